@@ -1,0 +1,219 @@
+"""ctypes binding of the C-ABI declared in include/beom_hip.h (libbeom_hip.so).
+
+This is the Python host's FFI stub — the same calls the Fortran host makes through
+iso_c_binding (beom_amd/host/beom_cabi.f95).  There is no fallback: if the HIP
+library is missing or no GPU is usable, `load()`/`Engine()` raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from .grid import Fields
+from .params import Params
+
+BEOM_MAX_LAYERS = 16
+BEOM_ABI_VERSION = 1
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libbeom_hip.so")
+
+
+class BeomParams(C.Structure):
+    """struct beom_params of include/beom_hip.h."""
+    _fields_ = (
+        [(n, C.c_int32) for n in ("abi_version", "lm", "mm", "nlay", "ndeg", "nsal", "variant",
+                                  "flag_nudging", "dense_hint")]
+        + [(n, C.c_double) for n in ("dl", "dt", "grav", "rho0", "beta", "epsi", "gamm", "del1",
+                                     "del2", "hmin", "hsal", "bvis", "dvis", "svis", "bdrg",
+                                     "tdrg", "qdrg", "hsbl", "hbbl", "g_fb", "uadv", "ocrp",
+                                     "rgld", "mcbc", "invf", "w_ti")]
+        + [("rhon", C.c_double * BEOM_MAX_LAYERS)]
+    )
+
+
+def make_params_struct(p: Params, f: Optional[Fields] = None, variant: int = 0,
+                       dense_hint: int = 1) -> BeomParams:
+    s = BeomParams()
+    s.abi_version = BEOM_ABI_VERSION
+    s.lm, s.mm, s.nlay, s.ndeg = p.lm, p.mm, p.nlay, p.ndeg
+    s.nsal = p.nsal
+    s.variant = variant
+    s.flag_nudging = int(bool(f.flag_nudging)) if f is not None else 0
+    s.dense_hint = dense_hint
+    for n in ("dl", "dt", "grav", "rho0", "beta", "epsi", "gamm", "del1", "del2", "hmin", "hsal",
+              "bvis", "dvis", "svis", "bdrg", "tdrg", "qdrg", "hsbl", "hbbl", "g_fb", "uadv",
+              "ocrp", "rgld", "mcbc"):
+        setattr(s, n, float(getattr(p, n)))
+    s.invf = float(f.invf) if f is not None else 0.0
+    s.w_ti = float(f.w_ti[0]) if f is not None else 0.0
+    if p.nlay > BEOM_MAX_LAYERS:
+        raise ValueError("nlay > BEOM_MAX_LAYERS")
+    for i, r in enumerate(p.rhon_v):
+        s.rhon[i] = float(r)
+    return s
+
+
+def _dp(a: Optional[np.ndarray]):
+    if a is None:
+        return None
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"], (a.dtype, a.flags)
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a: np.ndarray):
+    assert a.dtype == np.int32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+_lib = None
+ERRLEN = 999                       # lstr of shared_mod.f95:34
+
+
+def load(path: Optional[str] = None) -> C.CDLL:
+    """Loads libbeom_hip.so and declares every prototype of include/beom_hip.h."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise RuntimeError("HIP engine library %s not built (run __graft_entry__.build()); "
+                           "there is no CPU fallback" % path)
+    lib = C.CDLL(path)
+    dpp, ipp, cp, ci, cd = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_char_p, C.c_int, C.c_double
+    H = C.c_void_p
+    lib.beom_abi_version.restype = ci
+    lib.beom_device_count.argtypes = [cp, ci]
+    lib.beom_create.argtypes = [C.POINTER(BeomParams), ci, ipp, ipp] + [dpp] * 14 + [C.POINTER(H), cp, ci]
+    lib.beom_destroy.argtypes = [H]
+    lib.beom_upload_state.argtypes = [H] + [dpp] * 13 + [cp, ci]
+    lib.beom_download_state.argtypes = [H] + [dpp] * 13 + [cp, ci]
+    lib.beom_download_scratch.argtypes = [H] + [dpp] * 6 + [cp, ci]
+    lib.beom_step.argtypes = [H, ci, ci, cd, cd, cd, cd, ci, cp, ci]
+    lib.beom_sync.argtypes = [H, cp, ci]
+    lib.beom_update_h.argtypes = [H, cd, cd, cd]
+    lib.beom_update_mont_rvor_pvor_dive_kine.argtypes = [H, ci]
+    lib.beom_update_viscosity.argtypes = [H, ci]
+    lib.beom_update_u.argtypes = [H, ci, cd, cd, cd]
+    lib.beom_update_v.argtypes = [H, ci, cd, cd, cd]
+    lib.beom_rebuild_fluxes.argtypes = [H]
+    lib.beom_distribute_stress.argtypes = [H]
+    lib.beom_device_field.argtypes = [H, cp, C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
+                                      C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    lib.beom_is_dense.argtypes = [H]
+    lib.beom_profile_steps.argtypes = [H, ci, ci, cd, cd, cd, cd, ci, dpp, C.POINTER(ci), cp, ci]
+    for name in ("beom_device_count", "beom_create", "beom_destroy", "beom_upload_state",
+                 "beom_download_state", "beom_download_scratch", "beom_step", "beom_sync",
+                 "beom_update_h", "beom_update_mont_rvor_pvor_dive_kine", "beom_update_viscosity",
+                 "beom_update_u", "beom_update_v", "beom_rebuild_fluxes", "beom_distribute_stress",
+                 "beom_device_field", "beom_is_dense", "beom_profile_steps"):
+        getattr(lib, name).restype = ci
+    if lib.beom_abi_version() != BEOM_ABI_VERSION:
+        raise RuntimeError("ABI mismatch")
+    _lib = lib
+    return lib
+
+
+EXPORTS = ("beom_abi_version", "beom_device_count", "beom_create", "beom_destroy",
+           "beom_upload_state", "beom_download_state", "beom_download_scratch", "beom_step",
+           "beom_sync", "beom_update_h", "beom_update_mont_rvor_pvor_dive_kine",
+           "beom_update_viscosity", "beom_update_u", "beom_update_v", "beom_rebuild_fluxes",
+           "beom_distribute_stress", "beom_device_field", "beom_is_dense", "beom_profile_steps")
+
+STATE_NAMES = ("hlay", "u", "v", "h_u", "h_v", "rs_h", "dmdx", "dmdy", "v_cc", "v_ll",
+               "tt3d", "tb3d", "tu3d")
+SCRATCH_NAMES = ("mont", "rvor", "pvor", "dive", "d2hx", "d2hy")
+
+
+class BeomError(RuntimeError):
+    pass
+
+
+class Engine:
+    """One handle = one GPU's copy of the engine state (mirror of the Fortran module)."""
+
+    def __init__(self, f: Fields, device: int = 0, variant: int = 0, dense_hint: int = 1,
+                 upload: bool = True):
+        self.lib = load()
+        self.f = f
+        self.p = f.p
+        self.prm = make_params_struct(f.p, f, variant, dense_hint)
+        self._err = C.create_string_buffer(ERRLEN + 1)
+        self.h = C.c_void_p()
+        opt = lambda k: _dp(getattr(f, k)) if f.has.get(k, True) else None
+        rc = self.lib.beom_create(
+            C.byref(self.prm), device, _ip(f.neig), _ip(f.subc),
+            _dp(f.mk_u), _dp(f.mk_v), _dp(f.mk_n), _dp(f.mkpe), _dp(f.mkpi),
+            _dp(f.fcor), _dp(f.h_th), _dp(f.h_to), _dp(f.nudg), _dp(f.fnud),
+            opt("hdot"), opt("tide"), opt("bodf"), _dp(f.taus),
+            C.byref(self.h), self._err, ERRLEN)
+        self._check(rc)
+        if upload:
+            self.upload(**{k: getattr(f, k) for k in STATE_NAMES})
+
+    def _check(self, rc):
+        if rc != 0:
+            raise BeomError("beom_hip error %d: %s" % (rc, self._err.value.decode(errors="replace")))
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            self.lib.beom_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, **arrays):
+        args = [_dp(arrays.get(k)) for k in STATE_NAMES]
+        self._check(self.lib.beom_upload_state(self.h, *args, self._err, ERRLEN))
+
+    def download(self, names=STATE_NAMES) -> dict:
+        f = self.f
+        out = {k: np.zeros_like(getattr(f, k)) for k in names}
+        args = [_dp(out.get(k)) for k in STATE_NAMES]
+        self._check(self.lib.beom_download_state(self.h, *args, self._err, ERRLEN))
+        return out
+
+    def download_scratch(self) -> dict:
+        n1 = self.p.ndeg + 1
+        out = {k: np.zeros((self.p.nlay, n1)) for k in SCRATCH_NAMES}
+        self._check(self.lib.beom_download_scratch(self.h, *[_dp(out[k]) for k in SCRATCH_NAMES],
+                                                   self._err, ERRLEN))
+        return out
+
+    def step(self, tstp_first: int, nsteps: int, tres: float = 0.0, sync: bool = True):
+        p = self.p
+        self._check(self.lib.beom_step(self.h, tstp_first, nsteps, tres, float(p.dtd8),
+                                       float(p.dt_r), float(p.rsta), p.n_3d, self._err, ERRLEN))
+        if sync:
+            self.sync()
+
+    def sync(self):
+        self._check(self.lib.beom_sync(self.h, self._err, ERRLEN))
+
+    def profile_steps(self, tstp_first: int, nsteps: int, tres: float = 0.0):
+        p = self.p
+        ms = (C.c_double * 8)()
+        nl = (C.c_int * 8)()
+        self._check(self.lib.beom_profile_steps(self.h, tstp_first, nsteps, tres, float(p.dtd8),
+                                                float(p.dt_r), float(p.rsta), p.n_3d, ms, nl,
+                                                self._err, ERRLEN))
+        return list(ms)[:5], list(nl)[:5]
+
+    @property
+    def is_dense(self) -> bool:
+        return bool(self.lib.beom_is_dense(self.h))
+
+    # per-sweep entry points (parity tests)
+    def update_h(self, gene, ramp, ctim): self._check(self.lib.beom_update_h(self.h, gene, ramp, ctim))
+    def update_mont(self, ilay=0): self._check(self.lib.beom_update_mont_rvor_pvor_dive_kine(self.h, ilay))
+    def update_viscosity(self, ilay=0): self._check(self.lib.beom_update_viscosity(self.h, ilay))
+    def update_u(self, ilay, gene, ramp, ctim): self._check(self.lib.beom_update_u(self.h, ilay, gene, ramp, ctim))
+    def update_v(self, ilay, gene, ramp, ctim): self._check(self.lib.beom_update_v(self.h, ilay, gene, ramp, ctim))
+    def rebuild_fluxes(self): self._check(self.lib.beom_rebuild_fluxes(self.h))
+    def distribute_stress(self): self._check(self.lib.beom_distribute_stress(self.h))

@@ -1,0 +1,312 @@
+"""Input half of the testcases/*.m file contract, restated (no Octave in the image).
+
+Files are little-endian real*4, Fortran (column-major) order on the frame
+``(0:lm+1, 0:mm+1)`` exactly as ``read_input_file`` expects them
+(private_mod.f95:766-967):
+
+  h_bo.bin, fcor.bin  [lm+2, mm+2]          (:778)
+  taus.bin            [lm+2, mm+2, 2]       (:800)
+  nudg.bin            [lm+2, mm+2, 3]       (:785)   eta,u,v relaxation rates
+  hdot.bin            [lm+2, mm+2, nlay]    (:794)
+  init.bin            [lm+2, mm+2, nlay, 3] (:788)   interface eta, u, v
+  bodf.bin            [nlay, 2]             (:791)
+  tide.bin            [2, ncon, lm+2, mm+2, 3] (:797), omega at (1,k,0,0,1) (:953)
+
+Each ``case_*`` function follows the cited script's arithmetic on a grid size of the
+caller's choice and returns ``(Params, files)`` where ``files`` maps keyword →
+numpy array indexed ``[i, j, ...]`` (first index = x).  Arrays are float64 here and
+rounded to real*4 only when written, as Octave's ``fwrite(...,'real*4')`` does.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, Tuple
+
+import numpy as np
+
+from .params import Params, make_params
+
+HDRY = 1.0e-3
+
+
+def write_inputs(idir: str, files: Dict[str, np.ndarray]) -> None:
+    os.makedirs(idir, exist_ok=True)
+    for key, arr in files.items():
+        a = np.asarray(arr)
+        a.astype("<f4").ravel(order="F").tofile(os.path.join(idir, key + ".bin"))
+
+
+def read_input(idir: str, key: str, shape) -> np.ndarray | None:
+    path = os.path.join(idir, key + ".bin")
+    if not os.path.exists(path):
+        return None
+    a = np.fromfile(path, dtype="<f4")
+    return a.reshape(shape, order="F")
+
+
+def get_nbr_deg_freedom(h_bo: np.ndarray) -> int:
+    """testcases/get_nbr_deg_freedom.m:1-61 — count of packed cells."""
+    h = np.array(h_bo, dtype=np.float64)
+    h[h < 2.0 * HDRY] = 0.0
+    h[0, :] = 0.0; h[-1, :] = 0.0; h[:, 0] = 0.0; h[:, -1] = 0.0
+    lm, mm = h.shape[0] - 2, h.shape[1] - 2
+    hext = np.zeros((lm + 4, mm + 4))
+    hext[1:-1, 1:-1] = h
+    mask = (hext > HDRY).astype(np.int64)
+    neig = mask[1:-1, 1:-1] + mask[:-2, 1:-1] + mask[1:-1, :-2] + mask[:-2, :-2]
+    return int(np.count_nonzero(neig > 0))
+
+
+def _edge_replicate(inner: np.ndarray) -> np.ndarray:
+    """stommel1948.m:57-62 — embed [lm,mm,...] in [lm+2,mm+2,...] copying edges."""
+    shp = (inner.shape[0] + 2, inner.shape[1] + 2) + inner.shape[2:]
+    t = np.full(shp, np.nan)
+    t[1:-1, 1:-1] = inner
+    t[0, :] = t[1, :]
+    t[:, 0] = t[:, 1]
+    t[-1, :] = t[-2, :]
+    t[:, -1] = t[:, -2]
+    return t
+
+
+GRAV = 9.8
+
+
+# ---------------------------------------------------------------------------
+def case_stommel(lm: int = 100, mm: int = 63, dl: float = 100.0e3, dt_s: float = 40.0,
+                 dt_o: float = 1.0) -> Tuple[Params, Dict[str, np.ndarray]]:
+    """testcases/stommel1948.m:17-88 (BASELINE config 1).  The script's own size is
+    lm=round(1e7/dl)=100, mm=round(2*pi*1e6/dl)=63; other sizes keep lambda=lm*dl,
+    b=mm*dl."""
+    b = mm * dl if (lm, mm) != (100, 63) else 2.0 * np.pi * 1.0e6
+    rhon = 1027.0
+    hfla = 200.0
+    F = 0.1 / rhon
+    R = 2.0e-4
+    beta, fmin = 1.0e-11, 0.0
+    xx, yy = np.meshgrid((np.arange(lm) + 0.5) * dl, (np.arange(mm) + 0.5) * dl, indexing="ij")
+    h_bo = np.zeros((lm + 2, mm + 2))
+    h_bo[1:-1, 1:-1] = hfla
+    ndeg = get_nbr_deg_freedom(h_bo)
+    fcor = np.empty((lm, mm))
+    for j in range(1, mm + 1):
+        fcor[:, j - 1] = fmin + (j - 0.5) * dl * beta
+    tausx = -rhon * F * np.cos(np.pi * yy / b)
+    taus = np.stack([tausx, np.zeros_like(tausx)], axis=2)
+    cext = np.sqrt(GRAV * h_bo.max())
+    p = make_params(lm, mm, 1, ndeg, dl, cext, 0.0, [rhon], [0.0], dt_s, dt_o, 0.0, 0.0, 0.0,
+                    0.0, R, 1.0, 10.0, 10.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0,
+                    desc="Test-case for Stommel 1948")
+    # no h_bo.bin: the script relies on the default flat depth cext**2/grav (:121)
+    return p, {"fcor": _edge_replicate(fcor), "taus": _edge_replicate(taus)}
+
+
+def case_soliton(lm: int = 307, mm: int = 153, dt_s: float = 60.0, dt_o: float = 2.0
+                 ) -> Tuple[Params, Dict[str, np.ndarray]]:
+    """testcases/soliton.m:8-89 (BASELINE config 2).  The script has lx=6.12e6,
+    ly=3.06e6, dl=20e3 → 307×153; other sizes keep lx, ly and set dl=lx/lm."""
+    rhon, nlay, H = 1029.0, 1, 1.0
+    lx, ly = 0.5 * 12.24e6, 1.5 * 2.04e6
+    dl = 20.0e3 if (lm, mm) == (307, 153) else lx / lm
+    a_rd = 6371.0e3
+    omeg = 2.0 * np.pi / (24.0 * 3600.0)
+    x_0, parB = 0.0, 0.394
+    parA = 0.772 * parB ** 2
+    Elam = 4.0 * omeg ** 2 * a_rd ** 2 / GRAV / H
+    L_ls = a_rd / Elam ** 0.25
+    h_bo = np.zeros((lm + 2, mm + 2))
+    h_bo[1:-1, 1:-1] = H
+    ndeg = get_nbr_deg_freedom(h_bo)
+    xx, yy = np.meshgrid((np.arange(1, lm + 3) - 1.5) * dl, (np.arange(1, mm + 3) - 1.5) * dl,
+                         indexing="ij")
+    xx = xx - xx.mean()
+    yy = yy - yy.mean()
+    sech2 = 1.0 / np.cosh(parB * (xx - x_0) / L_ls) ** 2
+    ex = np.exp(-yy ** 2 / (2.0 * L_ls ** 2))
+    n = parA * H * sech2 * (6.0 * yy ** 2 + 3.0 * L_ls ** 2) / (4.0 * L_ls ** 2) * ex
+    u = parA * np.sqrt(GRAV * H) * sech2 * (6.0 * yy ** 2 - 9.0 * L_ls ** 2) / (4.0 * L_ls ** 2) * ex
+    v = (-2.0 * parA * parB * np.sqrt(GRAV * H) * np.tanh(parB * (xx - x_0) / L_ls) * sech2
+         * 2.0 * yy / L_ls * ex)
+    cext = np.sqrt(GRAV * (h_bo + n).max())
+    deld = 0.25 * ly / 40.0e6
+    beta = 2.0 * omeg * np.sin(np.deg2rad(deld)) - 2.0 * omeg * np.sin(np.deg2rad(-deld))
+    beta = beta / (2.0 * deld * 40.0e6 / 360.0)
+    fcor = beta * yy
+    init = np.stack([n[:, :, None], u[:, :, None], v[:, :, None]], axis=3)
+    p = make_params(lm, mm, nlay, ndeg, dl, cext, 0.0, [rhon], [0.0], dt_s, dt_o, 0.0, 0.0, 0.0,
+                    0.0, 0.0, 0.05, 10.0, 10.0, 1.0, 1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0,
+                    desc="Test-case for equatorial soliton")
+    return p, {"h_bo": h_bo, "fcor": fcor, "init": init}
+
+
+def case_unstable_jet(lm: int = 201, mm: int = 267, nlay: int = 1, dt_s: float = 50.0,
+                      dt_o: float = 2.0) -> Tuple[Params, Dict[str, np.ndarray]]:
+    """testcases/unstable_jet.m:10-66 (BASELINE config 3).  Script: 1 layer, dl=15e3,
+    lx=3000e3, ly=4000e3 → 201×267.  Other sizes keep lx and set dl=lx/lm.  For
+    nlay=2 (BASELINE asks for the multi-layer path; the script itself is 1-layer) the
+    column is split at topl=[0,0.5] with rhon=[1029,1030]; the jet is a surface
+    anomaly carried by every interface in proportion to its depth fraction."""
+    hshf = 5.0
+    lx = 3000.0e3
+    dl = 15.0e3 if (lm, mm) == (201, 267) else lx / lm
+    fcor = 0.5e-4
+    xx, yy = np.meshgrid(np.arange(1, lm + 3) - 1.5, np.arange(1, mm + 3) - 1.5, indexing="ij")
+    xx = xx - xx.mean()
+    yy = yy - yy.mean()
+    h_bo = hshf + 0.1 * hshf * np.cos(4.0 * np.pi * xx / lm)
+    h_bo[h_bo < 1.0] = 0.0
+    h_bo[0, :] = 0.0; h_bo[-1, :] = 0.0; h_bo[:, 0] = 0.0; h_bo[:, -1] = 0.0
+    if nlay > 1:
+        h_bo = np.where(h_bo > 0, hshf, 0.0)       # layered split needs flat bottom (ocrp=0 check :137-144)
+    cext = np.sqrt(GRAV * h_bo.max())
+    ndeg = get_nbr_deg_freedom(h_bo)
+    n = np.zeros((lm + 2, mm + 2, nlay))
+    u = np.zeros((lm + 2, mm + 2, nlay))
+    v = np.zeros((lm + 2, mm + 2, nlay))
+    n[:, :, 0] = 1.0 * np.exp(-yy ** 2 / (0.1 * mm) ** 2)
+    for iy in range(1, mm + 1):
+        u[:, iy, 0] = (n[:, iy + 1, 0] - n[:, iy - 1, 0]) / (2.0 * dl) * GRAV / abs(fcor) * (-1.0)
+    if nlay == 1:
+        rhon, topl = [1030.0], [0.0]
+    else:
+        rhon = [1029.0 + k for k in range(nlay)]
+        topl = [k / nlay for k in range(nlay)]
+        for k in range(1, nlay):
+            n[:, :, k] = n[:, :, 0] * (1.0 - topl[k])
+            u[:, :, k] = u[:, :, 0]
+    init = np.stack([n, u, v], axis=3)
+    p = make_params(lm, mm, nlay, ndeg, dl, cext, fcor, rhon, topl, dt_s, dt_o, 0.0, 0.0, 0.0,
+                    0.2, 0.0, 0.1, 10.0, 10.0, 1.0, 1.0, 0.0, 0.0, 0.0, 1.0, 1.0, 1.0,
+                    desc="Test-case for barotropic instability")
+    return p, {"h_bo": h_bo, "init": init}
+
+
+def case_sill_exchange3d(lm: int = 125, mm: int = 501, nlay: int = 2, dt_s: float = 30.0,
+                         dt_o: float = 0.01, npts: int = 15, sill_halfwidth: float = 50.0
+                         ) -> Tuple[Params, Dict[str, np.ndarray]]:
+    """testcases/sill_exchange3D.m:6-155 (BASELINE config 4).  Script: 2 layers,
+    dl=400, 125×501, rhon=[1027.47,1027.75], topl=[0,0.1428].  For nlay>2 extra
+    interfaces are inserted (rhon linear, topl = 0.1428·k), the initial anomaly goes
+    on the deepest interface as in the script."""
+    hmax, hsill = 700.0, 400.0
+    fcor = 0.00014087
+    dl = 400.0
+    if nlay == 2:
+        rhon, topl = [1027.47, 1027.75], [0.0, 0.1428]
+    else:
+        rhon = list(np.linspace(1027.47, 1027.75, nlay))
+        topl = [0.1428 * k for k in range(nlay)]
+    xx, yy = np.meshgrid(np.arange(1, lm + 3) - 1.5, np.arange(1, mm + 3) - 1.5, indexing="ij")
+    xx = xx * dl; yy = yy * dl
+    xx = xx - xx.mean(); yy = yy - yy.mean()
+    h_bo = hmax - hsill * np.exp(-(yy / (sill_halfwidth * dl)) ** 2)
+    ndeg = get_nbr_deg_freedom(h_bo)
+    cext = np.sqrt(GRAV * h_bo.max())
+    hsal = 5.0
+    hmin = hsal / 10.0
+    n = np.zeros((lm + 2, mm + 2, nlay)); u = np.zeros_like(n); v = np.zeros_like(n)
+    j0 = int(np.floor(0.6 * (mm + 2) + 0.5))          # Octave round()
+    n[:, j0:, nlay - 1] = np.minimum(-h_bo[:, j0:] + hmax - 100.0 + 4.0 * hsal, 0.0)
+    dt = 0.5 * dl / cext
+    widt = npts * dl
+    nort = np.zeros((lm + 2, mm + 2, 3)); sout = np.zeros_like(nort)
+    for j in range(1, mm + 3):
+        xpos = min(max(j - 1.5 + npts - mm, 0.0), npts - 0.5)
+        nort[:, j - 1, 1:3] = dt * cext / widt * xpos / (npts - xpos)
+        nort[:, j - 1, 0] = dt / (31.0 * 24.0 * 3600.0) * xpos / npts
+        xpos = min(max(npts - (j - 1.5), 0.0), npts - 0.5)
+        sout[:, j - 1, 1:3] = dt * cext / widt * xpos / (npts - xpos)
+        sout[:, j - 1, 0] = dt / (31.0 * 24.0 * 3600.0) * xpos / npts
+    nudg = np.maximum(nort, sout)
+    nudg[0, :, :] = 0.0
+    nudg[-1, :, :] = 0.0
+    init = np.stack([n, u, v], axis=3)
+    p = make_params(lm, mm, nlay, ndeg, dl, cext, fcor, rhon, topl, dt_s, dt_o, 0.0, 0.0, 0.0,
+                    0.9, 0.0, hmin, 5.0, 5.0, 1.0, 1.0, 1.0, 1.0, 0.0, 0.0, 0.0, 0.0,
+                    desc="Test-case: 3D sill exchange")
+    return p, {"init": init, "h_bo": h_bo, "nudg": nudg}
+
+
+def case_carrier_beach(lm: int | None = None, mm: int = 1, nlay: int = 1, dt_s: float = 0.08,
+                       dt_o: float = 5.0e-4, npts: int = 15) -> Tuple[Params, Dict[str, np.ndarray]]:
+    """testcases/carrier_beach.m:11-167 + its print_params call (wetting/drying,
+    ocrp=1; the recipe BASELINE config 5 extends in y).  For mm>1 the 1-D profile is
+    replicated along y.  For nlay>1 the column is split evenly in density."""
+    alph, l_0, epsi = 1.0e-3, 3.0e3, 0.1
+    dl = l_0 / 50.0
+    hhti = 3.0 * epsi * alph * l_0
+    l_x = 10.0 * l_0 + hhti / alph
+    lm0 = int(np.floor(l_x / dl + 0.5))
+    if lm is None:
+        lm = lm0
+    else:
+        dl = l_x / lm
+    hsal = 0.2 * alph * dl
+    hmin = hsal / 10.0
+    p_ = 1.0 / 8.0 / (1.0 + epsi)
+    prof = np.arange(lm + 1, -1, -1, dtype=np.float64) * dl * alph
+    h_bo = np.repeat(prof[:, None], mm + 2, axis=1)
+    h_bo[:npts, 1:-1] = h_bo[npts - 1, 1:-1]
+    h_bo[:, 0] = 0.0; h_bo[:, -1] = 0.0; h_bo[-1, :] = 0.0; h_bo[0, :] = 0.0
+    ndeg = get_nbr_deg_freedom(h_bo)
+    col = h_bo[:, 1]
+    d = np.abs(col - hhti)
+    i_sl = int(np.where(d == d.min())[0][0])
+    hhti = col[i_sl]
+    topl0 = hhti / h_bo.max()
+    cext = np.sqrt(GRAV * h_bo.max())
+    xref = np.arange(1, lm + 3, dtype=np.float64) * dl
+    xref = xref - xref[i_sl]
+    sigm = np.arange(10.0, -1e-9, -0.1)
+    x = 0.25 * epsi * np.exp(2) * p_ ** 2 * sigm ** 4 * np.exp(-sigm ** 2 * p_) - sigm ** 2 / 16.0
+    eta = 0.25 * epsi * p_ ** 2 * np.exp(2) * sigm ** 4 * np.exp(-sigm ** 2 * p_)
+    xs, es = x * l_0, eta * alph * l_0
+    order = np.argsort(xs)
+    n1 = np.interp(xref, xs[order], es[order], left=np.nan, right=np.nan)
+    n1[np.isnan(n1)] = 0.0
+    n = np.zeros((lm + 2, mm + 2, nlay)); u = np.zeros_like(n); v = np.zeros_like(n)
+    n[:, :, 0] = n1[:, None]
+    # western sponge on eta,u (carrier_beach.m:121-147)
+    nudg = np.zeros((lm + 2, mm + 2, 3))
+    dt = 0.5 * dl / cext
+    widt = npts * dl
+    for i in range(1, lm + 3):
+        xpos = min(max(npts - (i - 1.5), 0.0), npts - 0.5)
+        nudg[i - 1, :, 0:2] = dt * cext / widt * xpos / (npts - xpos)
+    if nlay == 1:
+        rhon, topl = [1030.0], [topl0]
+    else:
+        rhon = [1030.0 + 0.5 * k for k in range(nlay)]
+        topl = [topl0 + (1.0 - topl0) * k / nlay for k in range(nlay)]
+    init = np.stack([n, u, v], axis=3)
+    p = make_params(lm, mm, nlay, ndeg, dl, cext, 0.0, rhon, topl, dt_s, dt_o, 0.0, 0.0, 0.0,
+                    0.0, 0.0, hmin, 10.0, 10.0, 1.0, 1.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0,
+                    desc="Test-case for wave on sloping beach")
+    return p, {"h_bo": h_bo, "init": init, "nudg": nudg}
+
+
+def case_headline(lm: int = 4096, mm: int = 4096, nlay: int = 4, dvis: float = 0.2,
+                  nsteps_days: float | None = None) -> Tuple[Params, Dict[str, np.ndarray]]:
+    """SURVEY.md §8(d) headline: closed flat 4000 m basin, dl=1000, f0=1e-4,
+    rhon=1026+0.5k, topl=k/nlay, 1 m Gaussian surface mound of radius lm/12
+    (as conservation.m:75), g_fb=1, uadv=1, dvis=0.2, no forcing."""
+    dl, hfla, f0 = 1000.0, 4000.0, 1.0e-4
+    h_bo = np.zeros((lm + 2, mm + 2), dtype=np.float32)
+    h_bo[1:-1, 1:-1] = hfla
+    ndeg = (lm + 1) * (mm + 1)
+    cext = np.sqrt(GRAV * hfla)
+    rhon = [1026.0 + 0.5 * k for k in range(nlay)]
+    topl = [k / nlay for k in range(nlay)]
+    x = (np.arange(lm + 2, dtype=np.float64) - 0.5 * (lm + 1))[:, None]
+    y = (np.arange(mm + 2, dtype=np.float64) - 0.5 * (mm + 1))[None, :]
+    rad = lm / 12.0
+    mound = np.exp(-(x * x + y * y) / rad ** 2).astype(np.float32)
+    init = np.zeros((lm + 2, mm + 2, nlay, 3), dtype=np.float32)
+    for k in range(nlay):
+        init[:, :, k, 0] = mound * np.float32(1.0 - topl[k])
+    dt = 0.5 * dl / cext
+    dt_s = nsteps_days if nsteps_days is not None else 110.0 * dt / 86400.0
+    p = make_params(lm, mm, nlay, ndeg, dl, cext, f0, rhon, topl, dt_s, 1.0e3, 0.0, 0.0, 0.0,
+                    dvis, 0.0, 1.0, 10.0, 10.0, 1.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0,
+                    desc="Headline closed basin")
+    return p, {"h_bo": h_bo, "init": init}

@@ -1,0 +1,158 @@
+/*
+ * beom_hip.h — C-ABI of the MI355X-native BEOM time-step engine (libbeom_hip.so).
+ *
+ * The reference (zhazorken/beom) has no plugin/FFI interface: `program main` calls
+ * `run()` (main.f95:34) and the five hot routines communicate through module-global
+ * arrays (private_mod.f95:27-93).  The cut is therefore made one level above the hot
+ * routines, at the time step.  Each entry point below names the
+ * reference code it replaces.  Every array argument is a plain host pointer with the
+ * exact Fortran storage of the corresponding module array, index 0 (land sentinel)
+ * included:
+ *
+ *   X(0:ndeg, nlay)        -> x[ipnt + (ndeg+1)*(ilay-1)]
+ *   neig(8, 0:ndeg)        -> neig[(k-1) + 8*ipnt]           default integer (4 B)
+ *   rs_h(2, 0:ndeg, nlay)  -> rs_h[(m-1) + 2*(ipnt + (ndeg+1)*(ilay-1))]
+ *   dmdx(3, 0:ndeg, nlay)  -> dmdx[(m-1) + 3*(ipnt + (ndeg+1)*(ilay-1))]
+ *   fnud(0:ndeg, nlay, 3)  -> fnud[ipnt + (ndeg+1)*((ilay-1) + nlay*(ivar-1))]
+ *   nudg(0:ndeg, 3)        -> nudg[ipnt + (ndeg+1)*(ivar-1)]
+ *   tide(2, 1, 0:ndeg, 3)  -> tide[(m-1) + 2*(ipnt + (ndeg+1)*(ivar-1))]
+ *   tt3d(0:ndeg, 2, nlay)  -> tt3d[ipnt + (ndeg+1)*((idir-1) + 2*(ilay-1))]
+ *   bodf(nlay, 2)          -> bodf[(ilay-1) + nlay*(idir-1)]
+ *   taus(0:ndeg, 2)        -> taus[ipnt + (ndeg+1)*(idir-1)]
+ *
+ * Ownership: the caller owns every host array; the library copies at create/upload and
+ * never keeps a host pointer.  Device memory belongs to the handle.
+ * Errors: every function returns 0 on success and a negative code on failure, and
+ * writes a NUL-terminated message into errm (capacity errm_len; may be NULL) — the
+ * errc/errm convention of shared_mod.f95:113-157.  There is NO CPU fallback: without a
+ * usable HIP device beom_create fails.
+ * Threading: one host thread per handle, never from inside an OpenMP region
+ * (the reference calls the hot routines from the master thread, private_mod.f95:1867-1906).
+ */
+#ifndef BEOM_HIP_H
+#define BEOM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BEOM_MAX_LAYERS 16
+#define BEOM_ABI_VERSION 1
+
+/* Constants of shared_mod.f95:41-99, passed BY VALUE from the host so that the
+ * single-precision literals widened to double (grav = 9.8, beta = 0.281105, ...) keep
+ * the host compiler's bits.  Fortran side: type, bind(C) :: beom_params. */
+typedef struct beom_params {
+    int32_t abi_version;        /* BEOM_ABI_VERSION                                  */
+    int32_t lm, mm, nlay, ndeg; /* shared_mod.f95:41-45                              */
+    int32_t nsal;               /* shared_mod.f95:105 Salmon exponent (4)            */
+    int32_t variant;            /* 0: update_h of private_mod.f95:1593-1702;
+                                   1: epilogue of private_mod3d.f95:1635-1683        */
+    int32_t flag_nudging;       /* private_mod.f95:93,868-871                        */
+    int32_t dense_hint;         /* 1: let the library verify neig against the dense
+                                   closed form and use the fast path */
+    double dl, dt;              /* shared_mod.f95:47,84                              */
+    double grav, rho0;          /* :89-90                                            */
+    double beta, epsi, gamm, del1, del2; /* :91-95                                   */
+    double hmin, hsal;          /* :59,85                                            */
+    double bvis, dvis, svis;    /* :56-57 (+fork's svis)                             */
+    double bdrg, tdrg, qdrg;    /* :58,65 (+fork's tdrg)                             */
+    double hsbl, hbbl;          /* :60-61                                            */
+    double g_fb, uadv, ocrp, rgld, mcbc; /* :63-72                                   */
+    double invf;                /* private_mod.f95:223-229                           */
+    double w_ti;                /* private_mod.f95:85,953  tidal frequency (rad/day) */
+    double rhon[BEOM_MAX_LAYERS]; /* shared_mod.f95:50                               */
+} beom_params;
+
+typedef struct beom_engine *beom_handle;
+
+/* Version/ABI probe (no GPU needed). */
+int beom_abi_version(void);
+/* Number of visible HIP devices, or a negative error code. */
+int beom_device_count(char *errm, int errm_len);
+
+/* Replaces the static part of the module state built by read_input_data
+ * (private_mod.f95:105-250): connectivity (index_grid_points :567-764), masks,
+ * Coriolis, depth, and the optional forcings of read_input_file (:766-967).
+ * hdot, tide, bodf, taus, h_to may be NULL (= all zero, i.e. file absent). */
+int beom_create(const beom_params *prm, int device,
+                const int32_t *neig, const int32_t *subc,
+                const double *mk_u, const double *mk_v, const double *mk_n,
+                const double *mkpe, const double *mkpi,
+                const double *fcor, const double *h_th, const double *h_to,
+                const double *nudg, const double *fnud, const double *hdot,
+                const double *tide, const double *bodf, const double *taus,
+                beom_handle *out, char *errm, int errm_len);
+
+int beom_destroy(beom_handle h);
+
+/* Prognostic + history state, host -> device.  Any pointer may be NULL (left as is;
+ * a fresh handle holds the values of initialize_variables, private_mod.f95:252-307). */
+int beom_upload_state(beom_handle h,
+                      const double *hlay, const double *u, const double *v,
+                      const double *h_u, const double *h_v,
+                      const double *rs_h, const double *dmdx, const double *dmdy,
+                      const double *v_cc, const double *v_ll,
+                      const double *tt3d, const double *tb3d, const double *tu3d,
+                      char *errm, int errm_len);
+
+/* Device -> host; any pointer may be NULL.  Needed before write_outputs
+ * (private_mod.f95:1908-1910) and for restart/parity checks. */
+int beom_download_state(beom_handle h,
+                        double *hlay, double *u, double *v, double *h_u, double *h_v,
+                        double *rs_h, double *dmdx, double *dmdy,
+                        double *v_cc, double *v_ll,
+                        double *tt3d, double *tb3d, double *tu3d,
+                        char *errm, int errm_len);
+
+/* The six per-layer diagnostics of update_mont_rvor_pvor_dive_kine, which the library
+ * keeps per layer: each is (0:ndeg, nlay).  (The reference keeps (0:ndeg) and reuses it
+ * layer after layer, private_mod.f95:48-61.) */
+int beom_download_scratch(beom_handle h,
+                          double *mont, double *rvor, double *pvor, double *dive,
+                          double *d2hx, double *d2hy, char *errm, int errm_len);
+
+/* Replaces the body of integrate_time (private_mod.f95:1853-1912) for time steps
+ * tstp_first .. tstp_first+nsteps-1: ctim (:1862,1887), ramp (:1864-1866,1898-1901),
+ * gene (:1859,1877), distribute_stress cadence (:1863,1889-1896), and per step
+ * first_three_timesteps (:2151-2223) for tstp <= 3 or gener_forward_backward
+ * (:2225-2316) afterwards.  Asynchronous on the handle's stream; beom_sync to wait. */
+int beom_step(beom_handle h, int tstp_first, int nsteps,
+              double tres, double dtd8, double dt_r, double rsta, int n_3d,
+              char *errm, int errm_len);
+
+int beom_sync(beom_handle h, char *errm, int errm_len);
+
+/* Per-sweep entry points with the reference routines' meaning; used by parity tests.
+ * ilay is 1-based as in Fortran; ilay = 0 means "all layers" (one batched launch).
+ * The per-step scalars gene/ramp/ctim are module variables in the reference
+ * (private_mod.f95:70-73) and are passed explicitly here. */
+int beom_update_h(beom_handle h, double gene, double ramp, double ctim);          /* :1593 */
+int beom_update_mont_rvor_pvor_dive_kine(beom_handle h, int ilay);               /* :2318 */
+int beom_update_viscosity(beom_handle h, int ilay);                              /* :2441 */
+int beom_update_u(beom_handle h, int ilay, double gene, double ramp, double ctim); /* :1422 */
+int beom_update_v(beom_handle h, int ilay, double gene, double ramp, double ctim); /* :1505 */
+int beom_rebuild_fluxes(beom_handle h);                                          /* :2166-2177 */
+int beom_distribute_stress(beom_handle h);                                       /* :1921 */
+
+/* Introspection for measurement and zero-copy interop. */
+/* name in {hlay,u,v,h_u,h_v}: device pointer + layout of the library's internal copy.
+ * stride_layer/stride_row in elements; for the packed (gather) layout stride_row = 0. */
+int beom_device_field(beom_handle h, const char *name, void **dptr,
+                      int64_t *stride_layer, int64_t *stride_row, int64_t *row0_offset);
+/* 1 if the dense fast path is active for this handle, else 0. */
+int beom_is_dense(beom_handle h);
+/* Runs `nsteps` steps starting at tstp_first and returns the elapsed device time of
+ * each kernel class, measured with HIP events on the handle's stream:
+ * ms[0..4] = update_h, update_mont, update_viscosity, update_u, update_v (sums),
+ * launches[0..4] = number of launches in each class. */
+int beom_profile_steps(beom_handle h, int tstp_first, int nsteps,
+                       double tres, double dtd8, double dt_r, double rsta, int n_3d,
+                       double *ms, int *launches, char *errm, int errm_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BEOM_HIP_H */
