@@ -1,0 +1,89 @@
+"""Pins the oracle (oracle/beom_oracle.c) and the Python init mirror (beom_amd/grid.py)
+against golden vectors produced by the REAL reference (flang build of
+/root/reference, see tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+import oracle_lib
+from helpers import GOLDEN_STEPS, SCRATCH, STATE, Golden, golden_names, same
+
+NAMES = golden_names()
+
+
+def test_fixtures_present():
+    assert len(NAMES) >= 10
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_init_mirror_matches_reference_static_state(name):
+    """index_grid_points / h_0 / read_input_file mirror == reference module state
+    after read_input_data (private_mod.f95:105-250), bit for bit."""
+    g = Golden(name)
+    f = g.fields()
+    for k in ("neig", "subc", "mk_u", "mk_v", "mk_n", "mkpe", "mkpi", "h_th", "nudg", "fnud",
+              "hdot", "tide", "w_ti", "bodf", "taus", "hlay", "u", "v"):
+        assert same(getattr(f, k), g.static(k)), k
+    # fcor(0) is a real*4 SUM whose order is the compiler's (private_mod.f95:933): tolerance
+    assert same(f.fcor[1:], g.static("fcor")[1:])
+    assert abs(f.fcor[0] - g.static("fcor")[0]) <= 1e-5 * max(abs(g.static("fcor")).max(), 1e-30)
+    assert float(g.p.dt) == float(g.static("dt"))
+    grid = np.frombuffer(g.z["file_grid_bin"].tobytes(), dtype="<i4").reshape(5, -1)
+    assert np.array_equal(grid[0], f.posc)
+    h0 = np.frombuffer(g.z["file_h_0_bin"].tobytes(), dtype="<f4").reshape(g.p.nlay, -1)
+    assert np.array_equal(h0, f.h_0[:, 1:].astype(np.float32))
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_step_matches_reference_bitwise(name):
+    """oracle_step over steps 1..10 reproduces the reference's FP64 module state at
+    steps 1,2,3,4,5,10 exactly (first_three_timesteps, gene 0->g_fb, both U/V orders).
+    The scratch fields are the last layer's, as in the reference."""
+    g = Golden(name)
+    f = g.fields()
+    f.invf = float(g.static("invf"))           # see fcor(0) note above
+    o = oracle_lib.Oracle(f, variant=g.variant)
+    t = 0
+    for tgt in GOLDEN_STEPS:
+        o.step(t + 1, tgt - t)
+        t = tgt
+        st = o.state()
+        for k in STATE:
+            assert same(st[k], g.step(tgt, k)), (name, tgt, k)
+        for k in SCRATCH:
+            assert same(o.a[k], g.step(tgt, k)), (name, tgt, k)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_sweeps_compose_to_step(name):
+    """Per-sweep entry points called in the order of gener_forward_backward
+    (private_mod.f95:2259-2290) equal oracle_step."""
+    g = Golden(name)
+    f = g.fields()
+    f.invf = float(g.static("invf"))
+    a = oracle_lib.Oracle(f, variant=g.variant)
+    b = oracle_lib.Oracle(f, variant=g.variant)
+    a.step(1, 5)
+    p = g.p
+    for tstp in range(1, 6):
+        ctim = 0.0 + float(p.dtd8) * tstp
+        first3 = tstp <= 3
+        ramp = 1.0
+        c = float(p.dtd8) * (1 if first3 else tstp)
+        if float(p.rsta) < 0.5 and c < float(p.dt_r):
+            ramp = c / float(p.dt_r)
+        gene = 0.0 if first3 else float(p.g_fb)
+        upst = tstp == 1 or (not first3 and tstp % p.n_3d == 0)
+        if upst:
+            b.distribute_stress()
+        if first3:
+            b.rebuild_fluxes()
+        b.update_h(gene, ramp, ctim)
+        for il in range(1, p.nlay + 1):
+            b.update_mont(il)
+            if first3 or (float(p.dvis) > 1e-3 and upst):
+                b.update_viscosity(il)
+            order = ("u", "v") if tstp % 2 == 0 else ("v", "u")
+            for w in order:
+                getattr(b, "update_" + w)(il, gene, ramp, ctim)
+    for k in STATE:
+        assert same(a.state()[k], b.state()[k]), k
