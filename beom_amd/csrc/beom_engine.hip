@@ -1,0 +1,522 @@
+// beom_engine.hip — C-ABI of include/beom_hip.h: device state, uploads/downloads, the
+// step driver (integrate_time / first_three_timesteps / gener_forward_backward of the
+// reference, private_mod.f95:1840-1919, 2151-2316) and kernel launches.
+// No CPU fallback exists: every entry point needs a HIP device.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "beom_kernels.h"
+#include "beom_dense.h"
+
+namespace {
+
+void set_err(char *errm, int len, const char *fmt, ...) {
+    if (!errm || len <= 0) return;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(errm, (size_t)len, fmt, ap);
+    va_end(ap);
+}
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            set_err(errm, errm_len, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                    __FILE__, __LINE__);                                                    \
+            return -100 - (int)e_;                                                          \
+        }                                                                                   \
+    } while (0)
+
+}  // namespace
+
+struct beom_engine {
+    beom_params P;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    DevView d{};
+    bool dense = false;
+    std::vector<void *> allocs;
+    // geometry of the launches
+    dim3 grid_cells, grid_cells_layers, grid_cells0;
+    bool wind = false, bot = false, top = false;
+    char last_err[512] = {0};
+};
+
+namespace {
+
+template <class T>
+int dev_alloc(beom_engine *E, T **p, size_t n, char *errm, int errm_len, bool zero = true) {
+    void *q = nullptr;
+    HIP_TRY(hipMalloc(&q, n * sizeof(T)));
+    E->allocs.push_back(q);
+    if (zero) HIP_TRY(hipMemsetAsync(q, 0, n * sizeof(T), E->stream));
+    *p = (T *)q;
+    return 0;
+}
+
+template <class T>
+int dev_upload(beom_engine *E, const T **dst, const T *src, size_t n, char *errm, int errm_len) {
+    T *q = nullptr;
+    int rc = dev_alloc(E, &q, n, errm, errm_len, src == nullptr);
+    if (rc) return rc;
+    if (src) HIP_TRY(hipMemcpyAsync(q, src, n * sizeof(T), hipMemcpyHostToDevice, E->stream));
+    *dst = q;
+    return 0;
+}
+
+bool any_nonzero(const double *a, size_t n) {
+    if (!a) return false;
+    for (size_t i = 0; i < n; ++i)
+        if (a[i] != 0.0) return true;
+    return false;
+}
+
+struct HostNb {   // host twin of NbDense::at
+    int L, M, xper, yper;
+    int at(int a, int b) const {
+        if (xper) { if (a == 0) a = L - 1; else if (a == L) a = 1; }
+        if (yper) { if (b == 0) b = M - 1; else if (b == M) b = 1; }
+        return (a >= 1 && a <= L && b >= 1 && b <= M) ? (a + (b - 1) * L) : 0;
+    }
+};
+
+bool verify_dense(const beom_params &P, int xper, int yper, const int32_t *neig, const int32_t *subc) {
+    const int L = P.lm + 1, M = P.mm + 1;
+    if ((long long)P.ndeg != (long long)L * M) return false;
+    const HostNb nb{L, M, xper, yper};
+    static const int di[8] = {1, 1, 0, -1, -1, -1, 0, 1};
+    static const int dj[8] = {0, 1, 1, 1, 0, -1, -1, -1};
+    const long long n1 = (long long)P.ndeg + 1;
+    bool ok = true;
+    for (int j = 1; j <= M; ++j) {
+        for (int i = 1; i <= L; ++i) {
+            const long long ip = i + (long long)(j - 1) * L;
+            if (subc[ip] != i || subc[ip + n1] != j) ok = false;
+            for (int k = 0; k < 8; ++k)
+                if (neig[k + 8 * ip] != nb.at(i + di[k], j + dj[k])) ok = false;
+        }
+    }
+    return ok;
+}
+
+}  // namespace
+
+extern "C" {
+
+int beom_abi_version(void) { return BEOM_ABI_VERSION; }
+
+int beom_device_count(char *errm, int errm_len) {
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    return n;
+}
+
+int beom_create(const beom_params *prm, int device, const int32_t *neig, const int32_t *subc,
+                const double *mk_u, const double *mk_v, const double *mk_n, const double *mkpe,
+                const double *mkpi, const double *fcor, const double *h_th, const double *h_to,
+                const double *nudg, const double *fnud, const double *hdot, const double *tide,
+                const double *bodf, const double *taus, beom_handle *out, char *errm, int errm_len) {
+    if (!prm || !out) { set_err(errm, errm_len, "beom_create: null argument"); return -1; }
+    if (prm->abi_version != BEOM_ABI_VERSION) { set_err(errm, errm_len, "beom_create: ABI version mismatch (%d vs %d)", prm->abi_version, BEOM_ABI_VERSION); return -2; }
+    if (prm->nlay < 1 || prm->nlay > BEOM_MAX_LAYERS || prm->ndeg < 1 || prm->lm < 1 || prm->mm < 1) { set_err(errm, errm_len, "beom_create: bad sizes"); return -3; }
+    if (prm->svis > 0.0) { set_err(errm, errm_len, "beom_create: svis > 0 (biharmonic viscosity, private_mod.f95:2508-2599) is not implemented on the GPU path"); return -4; }
+    if (prm->rgld > 0.5) { set_err(errm, errm_len, "beom_create: rgld = 1 (rigid lid, private_mod.f95:1705-1838) is not implemented on the GPU path"); return -5; }
+    if (prm->flag_nudging && prm->mcbc < 0.5) { set_err(errm, errm_len, "beom_create: mcbc = 0 with nudging (no_gradient_obc, private_mod.f95:2613-2679) is not implemented on the GPU path"); return -6; }
+    if (prm->variant == 1 && prm->nlay < 3) { set_err(errm, errm_len, "beom_create: variant 1 (private_mod3d.f95) needs nlay >= 3"); return -7; }
+    if (!neig || !subc || !mk_u || !mk_v || !mk_n || !mkpe || !mkpi || !fcor || !h_th || !nudg || !fnud) { set_err(errm, errm_len, "beom_create: null static array"); return -1; }
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (ndev <= 0 || device < 0 || device >= ndev) { set_err(errm, errm_len, "beom_create: no usable HIP device (%d visible, asked for %d); there is no CPU fallback", ndev, device); return -8; }
+    HIP_TRY(hipSetDevice(device));
+    beom_engine *E = new beom_engine();
+    E->P = *prm;
+    E->device = device;
+    HIP_TRY(hipStreamCreateWithFlags(&E->stream, hipStreamNonBlocking));
+    DevView &d = E->d;
+    const size_t n1 = (size_t)prm->ndeg + 1, nl = (size_t)prm->nlay;
+    d.ndeg = prm->ndeg; d.nlay = prm->nlay; d.lm = prm->lm; d.mm = prm->mm; d.nsal = prm->nsal;
+    d.variant = prm->variant; d.n1 = (long long)n1;
+    d.L = prm->lm + 1; d.M = prm->mm + 1;
+    d.dl = prm->dl; d.dt = prm->dt; d.grav = prm->grav; d.rho0 = prm->rho0; d.beta = prm->beta;
+    d.epsi = prm->epsi; d.gamm = prm->gamm; d.del1 = prm->del1; d.del2 = prm->del2; d.hmin = prm->hmin;
+    d.hsal = prm->hsal; d.bvis = prm->bvis; d.dvis = prm->dvis; d.bdrg = prm->bdrg; d.tdrg = prm->tdrg;
+    d.qdrg = prm->qdrg; d.hsbl = prm->hsbl; d.hbbl = prm->hbbl; d.uadv = prm->uadv; d.ocrp = prm->ocrp;
+    d.rgld = prm->rgld; d.invf = prm->invf; d.w_ti = prm->w_ti;
+    for (int i = 0; i < BEOM_MAX_LAYERS; ++i) d.rhon[i] = prm->rhon[i];
+    // periodicity is encoded only in neig (private_mod.f95:614-685); recover it for the dense form
+    d.xper = 0; d.yper = 0;
+    E->dense = false;
+    if (prm->dense_hint && (long long)prm->ndeg == (long long)d.L * d.M) {
+        for (int xp = 0; xp < 2 && !E->dense; ++xp)
+            for (int yp = 0; yp < 2 && !E->dense; ++yp)
+                if (verify_dense(*prm, xp, yp, neig, subc)) { E->dense = true; d.xper = xp; d.yper = yp; }
+    }
+    int rc = 0;
+#define UP(name, src, n) if ((rc = dev_upload(E, &d.name, src, (size_t)(n), errm, errm_len))) { beom_destroy(E); return rc; }
+    UP(neig, neig, 8 * n1) UP(subc, subc, 2 * n1)
+    UP(mk_u, mk_u, n1) UP(mk_v, mk_v, n1) UP(mk_n, mk_n, n1) UP(mkpe, mkpe, n1) UP(mkpi, mkpi, n1)
+    UP(fcor, fcor, n1) UP(h_th, h_th, n1) UP(h_to, h_to, n1)
+    UP(nudg, nudg, 3 * n1) UP(fnud, fnud, 3 * nl * n1) UP(hdot, hdot, nl * n1)
+    UP(tide, tide, 6 * n1) UP(bodf, bodf, 2 * nl) UP(taus, taus, 2 * n1)
+#undef UP
+    d.has_hdot = any_nonzero(hdot, nl * n1);
+    d.has_tide = any_nonzero(tide, 6 * n1);
+    d.has_bodf = any_nonzero(bodf, 2 * nl);
+    d.has_nudg = any_nonzero(nudg, 3 * n1);
+    d.has_hto = any_nonzero(h_to, n1);
+    E->wind = false;
+    if (taus) for (size_t i = 0; i < 2 * n1; ++i) if (std::fabs(taus[i]) > 1.e-7) { E->wind = true; break; }   // :1945
+    E->bot = prm->bdrg > 1.e-7;                                                                                  // :1969
+    E->top = prm->tdrg > 1.e-7;                                                                                  // :1991
+    d.has_wind = E->wind;
+    d.has_stress = E->wind || E->bot || E->top;
+#define AL(name, n) if ((rc = dev_alloc(E, &d.name, (size_t)(n), errm, errm_len))) { beom_destroy(E); return rc; }
+    AL(hlay, nl * n1) AL(u, nl * n1) AL(v, nl * n1) AL(h_u, nl * n1) AL(h_v, nl * n1)
+    AL(rs[0], nl * n1) AL(rs[1], nl * n1)
+    AL(dmx[0], nl * n1) AL(dmx[1], nl * n1) AL(dmx[2], nl * n1)
+    AL(dmy[0], nl * n1) AL(dmy[1], nl * n1) AL(dmy[2], nl * n1)
+    AL(v_cc, nl * n1) AL(v_ll, nl * n1)
+    AL(tt3d, 2 * nl * n1) AL(tb3d, 2 * nl * n1) AL(tu3d, 2 * nl * n1)
+    AL(mont, nl * n1) AL(rvor, nl * n1) AL(pvor, nl * n1) AL(dive, nl * n1) AL(d2hx, nl * n1) AL(d2hy, nl * n1)
+    if (E->wind) AL(layt, nl * n1)
+    if (E->bot) { AL(layb, nl * n1) AL(taub, 2 * n1) }
+    if (E->top) { AL(layu, nl * n1) AL(taum, 2 * n1) }
+#undef AL
+    // initialize_variables: v_cc = v_ll = bvis everywhere, sentinel included (:276-277)
+    if (prm->bvis != 0.0) {
+        std::vector<double> b(nl * n1, prm->bvis);
+        HIP_TRY(hipMemcpyAsync(d.v_cc, b.data(), b.size() * sizeof(double), hipMemcpyHostToDevice, E->stream));
+        HIP_TRY(hipMemcpyAsync(d.v_ll, b.data(), b.size() * sizeof(double), hipMemcpyHostToDevice, E->stream));
+        HIP_TRY(hipStreamSynchronize(E->stream));
+    }
+    const unsigned gx = (unsigned)((prm->ndeg + BEOM_BLOCK - 1) / BEOM_BLOCK);
+    const unsigned gx0 = (unsigned)((prm->ndeg + 1 + BEOM_BLOCK - 1) / BEOM_BLOCK);
+    E->grid_cells = dim3(gx, 1, 1);
+    E->grid_cells_layers = dim3(gx, (unsigned)prm->nlay, 1);
+    E->grid_cells0 = dim3(gx0, 1, 1);
+    HIP_TRY(hipStreamSynchronize(E->stream));
+    *out = E;
+    return 0;
+}
+
+int beom_destroy(beom_handle E) {
+    if (!E) return 0;
+    (void)hipSetDevice(E->device);
+    if (E->stream) (void)hipStreamSynchronize(E->stream);
+    for (void *p : E->allocs) (void)hipFree(p);
+    if (E->stream) (void)hipStreamDestroy(E->stream);
+    delete E;
+    return 0;
+}
+
+// ---- host <-> device copies with the Fortran layouts ------------------------------
+static int copy_in(beom_engine *E, double *dst, const double *src, size_t n, char *errm, int errm_len) {
+    if (!src) return 0;
+    HIP_TRY(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyHostToDevice, E->stream));
+    return 0;
+}
+static int copy_out(beom_engine *E, double *dst, const double *src, size_t n, char *errm, int errm_len) {
+    if (!dst) return 0;
+    HIP_TRY(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToHost, E->stream));
+    return 0;
+}
+
+// AoS history (m, 0:ndeg, nlay) <-> K separate (0:ndeg, nlay) device arrays
+static int hist_in(beom_engine *E, double *const *dev, int K, const double *src, char *errm, int errm_len) {
+    if (!src) return 0;
+    const size_t n = (size_t)E->d.n1 * E->d.nlay;
+    std::vector<double> tmp(n);
+    for (int m = 0; m < K; ++m) {
+        for (size_t i = 0; i < n; ++i) tmp[i] = src[m + (size_t)K * i];
+        HIP_TRY(hipMemcpyAsync(dev[m], tmp.data(), n * sizeof(double), hipMemcpyHostToDevice, E->stream));
+        HIP_TRY(hipStreamSynchronize(E->stream));
+    }
+    return 0;
+}
+static int hist_out(beom_engine *E, double *const *dev, int K, double *dst, char *errm, int errm_len) {
+    if (!dst) return 0;
+    const size_t n = (size_t)E->d.n1 * E->d.nlay;
+    std::vector<double> tmp(n);
+    for (int m = 0; m < K; ++m) {
+        HIP_TRY(hipMemcpyAsync(tmp.data(), dev[m], n * sizeof(double), hipMemcpyDeviceToHost, E->stream));
+        HIP_TRY(hipStreamSynchronize(E->stream));
+        for (size_t i = 0; i < n; ++i) dst[m + (size_t)K * i] = tmp[i];
+    }
+    return 0;
+}
+
+int beom_upload_state(beom_handle E, const double *hlay, const double *u, const double *v,
+                      const double *h_u, const double *h_v, const double *rs_h, const double *dmdx,
+                      const double *dmdy, const double *v_cc, const double *v_ll, const double *tt3d,
+                      const double *tb3d, const double *tu3d, char *errm, int errm_len) {
+    if (!E) { set_err(errm, errm_len, "null handle"); return -1; }
+    HIP_TRY(hipSetDevice(E->device));
+    DevView &d = E->d;
+    const size_t n = (size_t)d.n1 * d.nlay;
+    int rc;
+    if ((rc = copy_in(E, d.hlay, hlay, n, errm, errm_len))) return rc;
+    if ((rc = copy_in(E, d.u, u, n, errm, errm_len))) return rc;
+    if ((rc = copy_in(E, d.v, v, n, errm, errm_len))) return rc;
+    if ((rc = copy_in(E, d.h_u, h_u, n, errm, errm_len))) return rc;
+    if ((rc = copy_in(E, d.h_v, h_v, n, errm, errm_len))) return rc;
+    if ((rc = copy_in(E, d.v_cc, v_cc, n, errm, errm_len))) return rc;
+    if ((rc = copy_in(E, d.v_ll, v_ll, n, errm, errm_len))) return rc;
+    if ((rc = copy_in(E, d.tt3d, tt3d, 2 * n, errm, errm_len))) return rc;
+    if ((rc = copy_in(E, d.tb3d, tb3d, 2 * n, errm, errm_len))) return rc;
+    if ((rc = copy_in(E, d.tu3d, tu3d, 2 * n, errm, errm_len))) return rc;
+    if ((rc = hist_in(E, d.rs, 2, rs_h, errm, errm_len))) return rc;
+    if ((rc = hist_in(E, d.dmx, 3, dmdx, errm, errm_len))) return rc;
+    if ((rc = hist_in(E, d.dmy, 3, dmdy, errm, errm_len))) return rc;
+    // a caller may upload stresses computed elsewhere: keep those terms live
+    if (any_nonzero(tt3d, 2 * n) || any_nonzero(tb3d, 2 * n) || any_nonzero(tu3d, 2 * n)) d.has_stress = 1;
+    HIP_TRY(hipStreamSynchronize(E->stream));
+    return 0;
+}
+
+int beom_download_state(beom_handle E, double *hlay, double *u, double *v, double *h_u, double *h_v,
+                        double *rs_h, double *dmdx, double *dmdy, double *v_cc, double *v_ll,
+                        double *tt3d, double *tb3d, double *tu3d, char *errm, int errm_len) {
+    if (!E) { set_err(errm, errm_len, "null handle"); return -1; }
+    HIP_TRY(hipSetDevice(E->device));
+    DevView &d = E->d;
+    const size_t n = (size_t)d.n1 * d.nlay;
+    int rc;
+    if ((rc = copy_out(E, hlay, d.hlay, n, errm, errm_len))) return rc;
+    if ((rc = copy_out(E, u, d.u, n, errm, errm_len))) return rc;
+    if ((rc = copy_out(E, v, d.v, n, errm, errm_len))) return rc;
+    if ((rc = copy_out(E, h_u, d.h_u, n, errm, errm_len))) return rc;
+    if ((rc = copy_out(E, h_v, d.h_v, n, errm, errm_len))) return rc;
+    if ((rc = copy_out(E, v_cc, d.v_cc, n, errm, errm_len))) return rc;
+    if ((rc = copy_out(E, v_ll, d.v_ll, n, errm, errm_len))) return rc;
+    if ((rc = copy_out(E, tt3d, d.tt3d, 2 * n, errm, errm_len))) return rc;
+    if ((rc = copy_out(E, tb3d, d.tb3d, 2 * n, errm, errm_len))) return rc;
+    if ((rc = copy_out(E, tu3d, d.tu3d, 2 * n, errm, errm_len))) return rc;
+    HIP_TRY(hipStreamSynchronize(E->stream));
+    if ((rc = hist_out(E, d.rs, 2, rs_h, errm, errm_len))) return rc;
+    if ((rc = hist_out(E, d.dmx, 3, dmdx, errm, errm_len))) return rc;
+    if ((rc = hist_out(E, d.dmy, 3, dmdy, errm, errm_len))) return rc;
+    return 0;
+}
+
+int beom_download_scratch(beom_handle E, double *mont, double *rvor, double *pvor, double *dive,
+                          double *d2hx, double *d2hy, char *errm, int errm_len) {
+    if (!E) { set_err(errm, errm_len, "null handle"); return -1; }
+    HIP_TRY(hipSetDevice(E->device));
+    DevView &d = E->d;
+    const size_t n = (size_t)d.n1 * d.nlay;
+    int rc;
+    if ((rc = copy_out(E, mont, d.mont, n, errm, errm_len))) return rc;
+    if ((rc = copy_out(E, rvor, d.rvor, n, errm, errm_len))) return rc;
+    if ((rc = copy_out(E, pvor, d.pvor, n, errm, errm_len))) return rc;
+    if ((rc = copy_out(E, dive, d.dive, n, errm, errm_len))) return rc;
+    if ((rc = copy_out(E, d2hx, d.d2hx, n, errm, errm_len))) return rc;
+    if ((rc = copy_out(E, d2hy, d.d2hy, n, errm, errm_len))) return rc;
+    HIP_TRY(hipStreamSynchronize(E->stream));
+    return 0;
+}
+
+int beom_sync(beom_handle E, char *errm, int errm_len) {
+    if (!E) { set_err(errm, errm_len, "null handle"); return -1; }
+    HIP_TRY(hipSetDevice(E->device));
+    HIP_TRY(hipStreamSynchronize(E->stream));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"
+
+// ---- launches -------------------------------------------------------------------------
+static inline void rot2(double *(&a)[2]) { double *t = a[0]; a[0] = a[1]; a[1] = t; }
+static inline void rot3(double *(&a)[3]) { double *t = a[0]; a[0] = a[1]; a[1] = a[2]; a[2] = t; }
+
+static void launch_rebuild(beom_engine *E) {
+    if (E->dense) hipLaunchKernelGGL(k_rebuild_fluxes<NbDense>, E->grid_cells_layers, dim3(BEOM_BLOCK), 0, E->stream, E->d);
+    else hipLaunchKernelGGL(k_rebuild_fluxes<NbGather>, E->grid_cells_layers, dim3(BEOM_BLOCK), 0, E->stream, E->d);
+}
+static void launch_h(beom_engine *E, double gene, double ramp, double ctim) {
+    // variant 1 couples layers inside a cell → one thread walks nlay..1; variant 0: one launch, layer = blockIdx.y
+    const dim3 g = (E->d.variant == 1) ? E->grid_cells : E->grid_cells_layers;
+    if (E->dense) {
+        if (!launch_dense_h(E->d, E->stream, gene, ramp, ctim))
+            hipLaunchKernelGGL(k_update_h<NbDense>, g, dim3(BEOM_BLOCK), 0, E->stream, E->d, gene, ramp, ctim, 0);
+    } else {
+        hipLaunchKernelGGL(k_update_h<NbGather>, g, dim3(BEOM_BLOCK), 0, E->stream, E->d, gene, ramp, ctim, 0);
+    }
+    rot2(E->d.rs);
+}
+static void launch_mont(beom_engine *E, int ilay) {
+    const dim3 g = ilay ? E->grid_cells : E->grid_cells_layers;
+    if (E->dense) {
+        if (ilay || !launch_dense_mont(E->d, E->stream))
+            hipLaunchKernelGGL(k_update_mont<NbDense>, g, dim3(BEOM_BLOCK), 0, E->stream, E->d, ilay);
+    } else {
+        hipLaunchKernelGGL(k_update_mont<NbGather>, g, dim3(BEOM_BLOCK), 0, E->stream, E->d, ilay);
+    }
+}
+static void launch_visc(beom_engine *E, int ilay) {
+    const dim3 g = ilay ? E->grid_cells : E->grid_cells_layers;
+    if (E->dense) {
+        if (ilay || !launch_dense_visc(E->d, E->stream))
+            hipLaunchKernelGGL(k_update_visc<NbDense>, g, dim3(BEOM_BLOCK), 0, E->stream, E->d, ilay);
+    } else {
+        hipLaunchKernelGGL(k_update_visc<NbGather>, g, dim3(BEOM_BLOCK), 0, E->stream, E->d, ilay);
+    }
+}
+template <bool XDIR>
+static void launch_uv(beom_engine *E, int ilay, double gene, double ramp, double ctim) {
+    const dim3 g = ilay ? E->grid_cells : E->grid_cells_layers;
+    const int copy_hist = ilay ? 1 : 0;       // a single-layer call cannot rotate shared pointers
+    if (E->dense) {
+        if (ilay || !launch_dense_uv<XDIR>(E->d, E->stream, gene, ramp, ctim))
+            hipLaunchKernelGGL((k_update_uv<NbDense, XDIR>), g, dim3(BEOM_BLOCK), 0, E->stream, E->d, ilay, gene, ramp, ctim, copy_hist);
+    } else {
+        hipLaunchKernelGGL((k_update_uv<NbGather, XDIR>), g, dim3(BEOM_BLOCK), 0, E->stream, E->d, ilay, gene, ramp, ctim, copy_hist);
+    }
+    if (!copy_hist) { if (XDIR) rot3(E->d.dmx); else rot3(E->d.dmy); }
+}
+static void launch_stress(beom_engine *E) {
+    if (!(E->wind || E->bot || E->top)) return;
+    const int w = E->wind, b = E->bot, t = E->top;
+    hipLaunchKernelGGL(k_stress_fractions, E->grid_cells0, dim3(BEOM_BLOCK), 0, E->stream, E->d, w, b, t);
+    for (int pass = 0; pass < 2; ++pass) {
+        if ((pass == 0 && !b) || (pass == 1 && !t)) continue;
+        if (E->dense) hipLaunchKernelGGL(k_stress_tau<NbDense>, E->grid_cells0, dim3(BEOM_BLOCK), 0, E->stream, E->d, pass);
+        else hipLaunchKernelGGL(k_stress_tau<NbGather>, E->grid_cells0, dim3(BEOM_BLOCK), 0, E->stream, E->d, pass);
+    }
+    if (E->dense) hipLaunchKernelGGL(k_stress_apply<NbDense>, E->grid_cells_layers, dim3(BEOM_BLOCK), 0, E->stream, E->d, w, b, t);
+    else hipLaunchKernelGGL(k_stress_apply<NbGather>, E->grid_cells_layers, dim3(BEOM_BLOCK), 0, E->stream, E->d, w, b, t);
+}
+
+extern "C" {
+
+#define NEED(E) do { if (!(E)) return -1; if (hipSetDevice((E)->device) != hipSuccess) return -9; } while (0)
+
+int beom_update_h(beom_handle E, double gene, double ramp, double ctim) { NEED(E); launch_h(E, gene, ramp, ctim); return 0; }
+int beom_update_mont_rvor_pvor_dive_kine(beom_handle E, int ilay) { NEED(E); if (ilay < 0 || ilay > E->d.nlay) return -3; launch_mont(E, ilay); return 0; }
+int beom_update_viscosity(beom_handle E, int ilay) { NEED(E); if (ilay < 0 || ilay > E->d.nlay) return -3; launch_visc(E, ilay); return 0; }
+int beom_update_u(beom_handle E, int ilay, double gene, double ramp, double ctim) { NEED(E); if (ilay < 0 || ilay > E->d.nlay) return -3; launch_uv<true>(E, ilay, gene, ramp, ctim); return 0; }
+int beom_update_v(beom_handle E, int ilay, double gene, double ramp, double ctim) { NEED(E); if (ilay < 0 || ilay > E->d.nlay) return -3; launch_uv<false>(E, ilay, gene, ramp, ctim); return 0; }
+int beom_rebuild_fluxes(beom_handle E) { NEED(E); launch_rebuild(E); return 0; }
+int beom_distribute_stress(beom_handle E) { NEED(E); launch_stress(E); return 0; }
+
+}  // extern "C"
+
+// Per-step scalars of integrate_time (private_mod.f95:1858-1901).
+struct StepScalars { double ctim, ramp, gene; bool first3, upst, stress; };
+static StepScalars step_scalars(const beom_engine *E, int tstp, double tres, double dtd8, double dt_r,
+                                double rsta, int n_3d) {
+    StepScalars s;
+    s.ctim = tres + dtd8 * (double)tstp;                           // :1862,1887
+    s.first3 = tstp <= 3;
+    s.ramp = 1.0;
+    if (s.first3) {
+        const double c1 = tres + dtd8 * 1.0;                       // ramp is set once, at tstp = 1 (:1864-1866)
+        if (rsta < 0.5 && c1 < dt_r) s.ramp = c1 / dt_r;
+        s.upst = true;                                             // update_viscosity is unconditional (:2188)
+        s.stress = tstp == 1;                                      // :1863
+    } else {
+        if (rsta < 0.5 && s.ctim < dt_r) s.ramp = s.ctim / dt_r;   // :1898-1901
+        s.upst = (tstp % n_3d) == 0;                               // :1889-1892
+        s.stress = s.upst;                                         // :1894-1896
+    }
+    s.gene = s.first3 ? 0.0 : E->P.g_fb;                           // :1859,1877
+    return s;
+}
+
+struct StepTimer {        // optional HIP-event bracket around each kernel class
+    std::vector<hipEvent_t> ev; std::vector<int> cls;
+    hipStream_t st;
+    void begin(int c) { hipEvent_t a; (void)hipEventCreate(&a); (void)hipEventRecord(a, st); ev.push_back(a); cls.push_back(c); }
+    void end() { hipEvent_t b; (void)hipEventCreate(&b); (void)hipEventRecord(b, st); ev.push_back(b); }
+};
+
+static void one_step(beom_engine *E, int tstp, const StepScalars &s, StepTimer *T) {
+    if (s.stress) launch_stress(E);
+    if (s.first3) launch_rebuild(E);                               // :2166-2177
+    if (T) T->begin(0);
+    launch_h(E, s.gene, s.ramp, s.ctim);                           // :2181,2259
+    if (T) { T->end(); T->begin(1); }
+    launch_mont(E, 0);                                             // :2187,2266
+    if (T) T->end();
+    if (s.first3 || (E->P.dvis > 1.e-3 && s.upst)) {               // :2188,2268
+        if (T) T->begin(2);
+        launch_visc(E, 0);
+        if (T) T->end();
+    }
+    if (tstp % 2 == 0) {                                           // :2193-2199,2276-2282
+        if (T) T->begin(3);
+        launch_uv<true>(E, 0, s.gene, s.ramp, s.ctim);
+        if (T) { T->end(); T->begin(4); }
+        launch_uv<false>(E, 0, s.gene, s.ramp, s.ctim);
+        if (T) T->end();
+    } else {
+        if (T) T->begin(4);
+        launch_uv<false>(E, 0, s.gene, s.ramp, s.ctim);
+        if (T) { T->end(); T->begin(3); }
+        launch_uv<true>(E, 0, s.gene, s.ramp, s.ctim);
+        if (T) T->end();
+    }
+}
+
+extern "C" {
+
+int beom_step(beom_handle E, int tstp_first, int nsteps, double tres, double dtd8, double dt_r,
+              double rsta, int n_3d, char *errm, int errm_len) {
+    if (!E) { set_err(errm, errm_len, "null handle"); return -1; }
+    if (tstp_first < 1 || nsteps < 0 || n_3d < 1) { set_err(errm, errm_len, "beom_step: bad arguments"); return -3; }
+    HIP_TRY(hipSetDevice(E->device));
+    for (int tstp = tstp_first; tstp < tstp_first + nsteps; ++tstp)
+        one_step(E, tstp, step_scalars(E, tstp, tres, dtd8, dt_r, rsta, n_3d), nullptr);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int beom_profile_steps(beom_handle E, int tstp_first, int nsteps, double tres, double dtd8, double dt_r,
+                       double rsta, int n_3d, double *ms, int *launches, char *errm, int errm_len) {
+    if (!E || !ms || !launches) { set_err(errm, errm_len, "null argument"); return -1; }
+    HIP_TRY(hipSetDevice(E->device));
+    StepTimer T; T.st = E->stream;
+    for (int tstp = tstp_first; tstp < tstp_first + nsteps; ++tstp)
+        one_step(E, tstp, step_scalars(E, tstp, tres, dtd8, dt_r, rsta, n_3d), &T);
+    HIP_TRY(hipStreamSynchronize(E->stream));
+    for (int c = 0; c < 5; ++c) { ms[c] = 0.0; launches[c] = 0; }
+    for (size_t k = 0; k < T.cls.size(); ++k) {
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, T.ev[2 * k], T.ev[2 * k + 1]);
+        ms[T.cls[k]] += (double)t;
+        launches[T.cls[k]] += 1;
+    }
+    for (hipEvent_t e : T.ev) (void)hipEventDestroy(e);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int beom_is_dense(beom_handle E) { return (E && E->dense) ? 1 : 0; }
+
+int beom_device_field(beom_handle E, const char *name, void **dptr, int64_t *stride_layer,
+                      int64_t *stride_row, int64_t *row0_offset) {
+    if (!E || !name || !dptr) return -1;
+    const DevView &d = E->d;
+    double *p = nullptr;
+    if (!strcmp(name, "hlay")) p = d.hlay;
+    else if (!strcmp(name, "u")) p = d.u;
+    else if (!strcmp(name, "v")) p = d.v;
+    else if (!strcmp(name, "h_u")) p = d.h_u;
+    else if (!strcmp(name, "h_v")) p = d.h_v;
+    else return -3;
+    *dptr = p;
+    if (stride_layer) *stride_layer = d.n1;
+    if (stride_row) *stride_row = E->dense ? d.L : 0;
+    if (row0_offset) *row0_offset = 1;
+    return 0;
+}
+
+}  // extern "C"

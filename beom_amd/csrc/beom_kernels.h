@@ -1,0 +1,352 @@
+// beom_kernels.h — the five sweeps of the BEOM time step as HIP kernels (gfx950).
+//
+// One thread = one packed cell of one layer (layer = blockIdx.y + 1 unless the sweep
+// couples layers).  Every kernel is a template over the neighbour lookup (NbGather:
+// any coastline, via the neig table; NbDense: index arithmetic, no table traffic).
+// Arithmetic follows the reference statement by statement and in its operation order
+// (compiled with -ffp-contract=off) so results are bit-identical to the Fortran.
+// HBM-bound FP64 stencils: no MFMA (nothing here is a contraction).
+#pragma once
+#include "beom_dev.h"
+
+#define BEOM_BLOCK 256
+
+#define LL(a, ip, il) (a)[(long long)(ip) + d.n1 * (long long)((il) - 1)]
+#define FNUD_(ip, il, iv) d.fnud[(long long)(ip) + d.n1 * ((long long)((il) - 1) + (long long)d.nlay * ((iv) - 1))]
+#define NUDG_(ip, iv) d.nudg[(long long)(ip) + d.n1 * ((iv) - 1)]
+#define TIDE_(m, ip, iv) d.tide[((m) - 1) + 2 * ((long long)(ip) + d.n1 * ((iv) - 1))]
+#define T3_(a, ip, id, il) (a)[(long long)(ip) + d.n1 * ((long long)((id) - 1) + 2 * (long long)((il) - 1))]
+
+__device__ __forceinline__ double powi_dev(double x, int n) {   // REAL**INTEGER, repeated squaring
+    double result = 1.0, base = x;
+    bool first = true;
+    while (n) {
+        if (n & 1) { result = first ? base : result * base; first = false; }
+        n >>= 1;
+        if (n) base = base * base;
+    }
+    return result;
+}
+
+// ---- first_three_timesteps prologue, private_mod.f95:2166-2177 ---------------------
+template <class NB>
+__global__ __launch_bounds__(BEOM_BLOCK) void k_rebuild_fluxes(DevView d) {
+    const int ipnt = blockIdx.x * BEOM_BLOCK + threadIdx.x + 1;
+    const int ilay = blockIdx.y + 1;
+    if (ipnt > d.ndeg) return;
+    NB nb(d, ipnt);
+    const int c5 = nb.template get<5>(), c7 = nb.template get<7>();
+    const double h0 = LL(d.hlay, ipnt, ilay);
+    LL(d.h_u, ipnt, ilay) = LL(d.u, ipnt, ilay) * (h0 + LL(d.hlay, c5, ilay)) / (1.0 + d.mk_u[ipnt]);
+    LL(d.h_v, ipnt, ilay) = LL(d.v, ipnt, ilay) * (h0 + LL(d.hlay, c7, ilay)) / (1.0 + d.mk_v[ipnt]);
+}
+
+// ---- update_h, private_mod.f95:1593-1646; variant 1 = private_mod3d.f95:1635-1683 ---
+// Layers nlay..1 are walked inside the thread (variant 1 reads hlay(ipnt,3) across layers).
+template <class NB>
+__global__ __launch_bounds__(BEOM_BLOCK) void k_update_h(DevView d, double gene, double ramp,
+                                                         double ctim, int copy_hist) {
+    const int ipnt = blockIdx.x * BEOM_BLOCK + threadIdx.x + 1;
+    if (ipnt > d.ndeg) return;
+    NB nb(d, ipnt);
+    const int c1 = nb.template get<1>(), c3 = nb.template get<3>();
+    const double i_dl = 1.0 / d.dl;
+    const double mkn = d.mk_n[ipnt];
+    const double ng = d.has_nudg ? NUDG_(ipnt, 1) : 0.0;
+    const int ilay_hi = gridDim.y == 1 ? d.nlay : (int)blockIdx.y + 1;
+    const int ilay_lo = gridDim.y == 1 ? 1 : (int)blockIdx.y + 1;
+    for (int ilay = ilay_hi; ilay >= ilay_lo; --ilay) {
+        double hold = LL(d.hlay, ipnt, ilay);
+        double rs_3 = (LL(d.h_u, ipnt, ilay) - LL(d.h_u, c1, ilay)) * i_dl
+                    + (LL(d.h_v, ipnt, ilay) - LL(d.h_v, c3, ilay)) * i_dl
+                    + (d.has_hdot ? LL(d.hdot, ipnt, ilay) : 0.0);
+        rs_3 = rs_3 * mkn;
+        const double r2 = LL(d.rs[1], ipnt, ilay);
+        double rhsi;
+        if (gene != 0.0) {
+            const double r1 = LL(d.rs[0], ipnt, ilay);
+            rhsi = ((1.5 + d.beta) * rs_3 - (0.5 + 2.0 * d.beta) * r2 + d.beta * r1) * d.dt * gene
+                 + rs_3 * d.dt * (1.0 - gene);
+        } else {
+            rhsi = rs_3 * d.dt;               // (..)*dt*0 + rs_3*dt*(1-0)
+        }
+        hold = hold + rhsi;
+        double hnew = hold;
+        if (d.has_nudg) {
+            double hfor = FNUD_(ipnt, ilay, 1);
+            if (d.has_tide) {
+                const double vecl = (ilay == 1) ? 1.0 : 0.0;
+                hfor = hfor + ramp * TIDE_(1, ipnt, 1) * vecl * cos(TIDE_(2, ipnt, 1) - d.w_ti * ctim);
+            }
+            if (d.variant == 0) {
+                hnew = hfor * ng + (1.0 - ng) * hold;
+            } else {
+                const double hfor1 = 0.0, hfor2 = 800.0, hfor3 = 0.0;
+                const int isub = d.subc[ipnt];
+                const int half = d.lm / 2;
+                const double h3v = (ilay == 3) ? hold : LL(d.hlay, ipnt, 3);
+                double hl = hold;
+                if (h3v > 20.0 * d.hsal && isub > half) {
+                    if (ilay == 1)      hl = hl + 0.0 * ng + fmax(hfor1 * ng + (-ng) * hl, 0.0);
+                    else if (ilay == 2) hl = hl + 0.0 * ng + fmax(hfor2 * ng + (-ng) * hl, 0.0);
+                    else if (ilay == 3) hl = hl - 0.0 * ng + fmin(hfor3 * ng + (-ng) * hl, 0.0);
+                } else if (h3v < 20.0 * d.hsal && isub > half) {
+                    if (ilay == 1)      hl = hl + 0.0 * ng + 1.0 * fmax(hfor2 * ng + (-ng) * hl, 0.0);
+                    else if (ilay == 2) hl = hl - 0.0 * ng + 1.0 * fmin(hfor1 * ng + (-ng) * hl, 0.0);
+                }
+                if (isub < half) hl = hfor * ng + (1.0 - ng) * hold;
+                hnew = hl;
+            }
+        }
+        LL(d.hlay, ipnt, ilay) = hnew;
+        if (copy_hist) {
+            LL(d.rs[0], ipnt, ilay) = r2;
+            LL(d.rs[1], ipnt, ilay) = rs_3;
+        } else {
+            LL(d.rs[0], ipnt, ilay) = rs_3;   // host swaps rs[0] <-> rs[1] afterwards
+        }
+    }
+}
+
+// ---- update_mont_rvor_pvor_dive_kine, private_mod.f95:2318-2439 ---------------------
+template <class NB>
+__global__ __launch_bounds__(BEOM_BLOCK) void k_update_mont(DevView d, int ilay_only) {
+    const int ipnt = blockIdx.x * BEOM_BLOCK + threadIdx.x + 1;
+    const int ilay = ilay_only ? ilay_only : (int)blockIdx.y + 1;
+    if (ipnt > d.ndeg) return;
+    NB nb(d, ipnt);
+    const int c1 = nb.template get<1>(), c3 = nb.template get<3>(), c5 = nb.template get<5>(),
+              c6 = nb.template get<6>(), c7 = nb.template get<7>();
+    const double i_dl = 1.0 / d.dl, i_gr = 1.0 / d.grav;
+    const double i_ns = 1.0 / (double)(d.nsal - 1);
+    const double hs_8 = d.hsal;
+    const double u_le = LL(d.u, ipnt, ilay), u_ri = LL(d.u, c1, ilay);
+    const double v_bo = LL(d.v, ipnt, ilay), v_to = LL(d.v, c3, ilay);
+    const double mkn = d.mk_n[ipnt];
+    const double h0 = LL(d.hlay, ipnt, ilay);
+    double mpot = h0 + d.hmin * (1.0 - mkn);
+    mpot = powi_dev(d.hsal / mpot, d.nsal - 1);
+    mpot = mpot * (-d.ocrp * i_ns * d.hsal * mkn);
+    mpot = mpot - (d.has_hto ? d.h_to[ipnt] : 0.0);
+    const double i_rn = 1.0 / d.rhon[ilay - 1];
+    for (int i = 1; i <= ilay - 1; ++i)
+        mpot = mpot - (d.rhon[ilay - 1] - d.rhon[i - 1]) * i_rn * LL(d.hlay, ipnt, i);
+    if (d.rgld < 0.5) {
+        double hcol = 0.0;
+        for (int i = 1; i <= d.nlay; ++i) hcol = hcol + LL(d.hlay, ipnt, i);
+        mpot = hcol - d.h_th[ipnt] + mpot;
+    }
+    LL(d.mont, ipnt, ilay) = mpot + 0.25 * d.uadv * i_gr
+                                  * (u_ri * u_ri + u_le * u_le + v_to * v_to + v_bo * v_bo);
+    const double rv = (v_bo - LL(d.v, c5, ilay) - u_le + LL(d.u, c7, ilay)) * i_dl * d.mkpe[ipnt];
+    LL(d.rvor, ipnt, ilay) = rv;
+    const double hE = LL(d.hlay, c1, ilay), hW = LL(d.hlay, c5, ilay),
+                 hN = LL(d.hlay, c3, ilay), hS = LL(d.hlay, c7, ilay);
+    const double mk1 = d.mk_n[c1], mk3 = d.mk_n[c3], mk5 = d.mk_n[c5], mk6 = d.mk_n[c6], mk7 = d.mk_n[c7];
+    double d2x = (hE + hW - h0 * 2.0) * mk1 * mk5 * mkn;
+    double d2y = (hN + hS - h0 * 2.0) * mk3 * mk7 * mkn;
+    if (d.ocrp > 0.5) {
+        if (hE < 2.0 * hs_8 || hW < 2.0 * hs_8 || h0 < 2.0 * hs_8) d2x = 0.0;
+        if (hN < 2.0 * hs_8 || hS < 2.0 * hs_8 || h0 < 2.0 * hs_8) d2y = 0.0;
+    }
+    LL(d.d2hx, ipnt, ilay) = d2x;
+    LL(d.d2hy, ipnt, ilay) = d2y;
+    const double have = h0 + hW + LL(d.hlay, c6, ilay) + hS;
+    LL(d.pvor, ipnt, ilay) = (d.fcor[ipnt] + rv * d.uadv) * d.mkpi[ipnt] * (mkn + mk5 + mk6 + mk7) / have;
+    LL(d.dive, ipnt, ilay) = (u_ri - u_le + v_to - v_bo) * i_dl;
+}
+
+// ---- update_viscosity (Leith part), private_mod.f95:2441-2502 -----------------------
+template <class NB>
+__global__ __launch_bounds__(BEOM_BLOCK) void k_update_visc(DevView d, int ilay_only) {
+    const int ipnt = blockIdx.x * BEOM_BLOCK + threadIdx.x + 1;
+    const int ilay = ilay_only ? ilay_only : (int)blockIdx.y + 1;
+    if (ipnt > d.ndeg) return;
+    NB nb(d, ipnt);
+    const int c1 = nb.template get<1>(), c2 = nb.template get<2>(), c3 = nb.template get<3>(),
+              c5 = nb.template get<5>(), c6 = nb.template get<6>(), c7 = nb.template get<7>();
+    const double r_bl = LL(d.rvor, ipnt, ilay), r_br = LL(d.rvor, c1, ilay), r_tr = LL(d.rvor, c2, ilay),
+                 r_tl = LL(d.rvor, c3, ilay), rbll = LL(d.rvor, c5, ilay), rbbl = LL(d.rvor, c7, ilay);
+    const double d_cc = LL(d.dive, ipnt, ilay), d_ri = LL(d.dive, c1, ilay), d_to = LL(d.dive, c3, ilay),
+                 d_le = LL(d.dive, c5, ilay), d_bl = LL(d.dive, c6, ilay), d_bo = LL(d.dive, c7, ilay);
+    double a = (r_br - r_bl) * (r_br - r_bl) + (r_bl - rbll) * (r_bl - rbll)
+             + (r_tl - r_bl) * (r_tl - r_bl) + (r_bl - rbbl) * (r_bl - rbbl)
+             + (d_cc - d_le) * (d_cc - d_le) + (d_bo - d_bl) * (d_bo - d_bl)
+             + (d_cc - d_bo) * (d_cc - d_bo) + (d_le - d_bl) * (d_le - d_bl);
+    LL(d.v_ll, ipnt, ilay) = sqrt(a) * d.dvis * d.dl * d.dl + d.bvis;
+    double b = (r_br - r_bl) * (r_br - r_bl) + (r_tr - r_tl) * (r_tr - r_tl)
+             + (r_tl - r_bl) * (r_tl - r_bl) + (r_tr - r_br) * (r_tr - r_br)
+             + (d_ri - d_cc) * (d_ri - d_cc) + (d_cc - d_le) * (d_cc - d_le)
+             + (d_to - d_cc) * (d_to - d_cc) + (d_cc - d_bo) * (d_cc - d_bo);
+    LL(d.v_cc, ipnt, ilay) = sqrt(b) * d.dvis * d.dl * d.dl + d.bvis;
+}
+
+// ---- update_u (XDIR=true, private_mod.f95:1422-1503) and update_v (XDIR=false,
+//      :1505-1591).  The two routines are mirror images: W<->S, N<->E, NW<->SE. -------
+template <class NB, bool XDIR>
+__global__ __launch_bounds__(BEOM_BLOCK) void k_update_uv(DevView d, int ilay_only, double gene,
+                                                          double ramp, double ctim, int copy_hist) {
+    const int ipnt = blockIdx.x * BEOM_BLOCK + threadIdx.x + 1;
+    const int ilay = ilay_only ? ilay_only : (int)blockIdx.y + 1;
+    if (ipnt > d.ndeg) return;
+    NB nb(d, ipnt);
+    // u: cb = W(5), ca = N(3), cd = NW(4);   v: cb = S(7), ca = E(1), cd = SE(8)
+    const int cb = XDIR ? nb.template get<5>() : nb.template get<7>();
+    const int ca = XDIR ? nb.template get<3>() : nb.template get<1>();
+    const int cd = XDIR ? nb.template get<4>() : nb.template get<8>();
+    const double *mk = XDIR ? d.mk_u : d.mk_v;
+    double *vel = XDIR ? d.u : d.v;
+    const double *hq = XDIR ? d.h_v : d.h_u;       // the transport of the OTHER component
+    double *hp = XDIR ? d.h_u : d.h_v;
+    const double *d2h = XDIR ? d.d2hx : d.d2hy;
+    double *const *dm = XDIR ? d.dmx : d.dmy;
+    constexpr int IV = XDIR ? 2 : 3;               // ix_u / ix_v
+    constexpr int ID = XDIR ? 1 : 2;               // stress component of this direction
+    constexpr int IO = XDIR ? 2 : 1;               // the other one (Ekman term of ufor/vfor)
+    const double i_dl = 1.0 / d.dl, i_r0 = 1.0 / d.rho0, i_r1 = 1.0 / d.rhon[0];
+    const double mask = mk[ipnt];
+    const double hcen = XDIR ? (LL(d.hlay, cb, ilay) + LL(d.hlay, ipnt, ilay)) / (1.0 + mask)
+                             : (LL(d.hlay, ipnt, ilay) + LL(d.hlay, cb, ilay)) / (1.0 + mask);
+    const double i__h = 1.0 / (hcen + 1.0 - mask);
+    double vold = LL(vel, ipnt, ilay);
+    const double dmd4 = (LL(d.mont, cb, ilay) - LL(d.mont, ipnt, ilay)) * i_dl * d.grav * mask;
+    const double pv0 = LL(d.pvor, ipnt, ilay), pva = LL(d.pvor, ca, ilay);
+    const double q0 = LL(hq, ipnt, ilay), qb = LL(hq, cb, ilay), qa = LL(hq, ca, ilay), qd = LL(hq, cd, ilay);
+    double rhsi = dmd4 * (1.0 - gene);
+    if (XDIR) rhsi = rhsi + 0.25 * pv0 * (q0 + qb) + 0.25 * pva * (qa + qd);
+    else      rhsi = rhsi - 0.25 * pv0 * (q0 + qb) - 0.25 * pva * (qa + qd);
+    if (d.has_stress) {
+        const double tauw = 0.5 * (T3_(d.tt3d, cb, ID, ilay) + T3_(d.tt3d, ipnt, ID, ilay)) * ramp;
+        rhsi = rhsi + tauw * i_r0 * i__h;
+        rhsi = rhsi - T3_(d.tb3d, ipnt, ID, ilay) * i_r0 * i__h;
+        rhsi = rhsi - T3_(d.tu3d, ipnt, ID, ilay) * i_r0 * i__h;
+    }
+    if (d.has_bodf) rhsi = rhsi + d.bodf[(ilay - 1) + d.nlay * (ID - 1)];
+    if (gene != 0.0) {
+        rhsi = rhsi + (d.del1 * dmd4 + d.del2 * LL(dm[2], ipnt, ilay) + d.gamm * LL(dm[1], ipnt, ilay)
+                       + d.epsi * LL(dm[0], ipnt, ilay)) * gene;
+    }
+    {
+        const double vc0 = LL(d.v_cc, ipnt, ilay), vcb = LL(d.v_cc, cb, ilay);
+        const double vl0 = LL(d.v_ll, ipnt, ilay), vla = LL(d.v_ll, ca, ilay);
+        const double dv0 = LL(d.dive, ipnt, ilay), dvb = LL(d.dive, cb, ilay);
+        const double rv0 = LL(d.rvor, ipnt, ilay), rva = LL(d.rvor, ca, ilay);
+        if (XDIR) rhsi = rhsi + (vc0 * dv0 - vcb * dvb) * i_dl - (vla * rva - vl0 * rv0) * i_dl;
+        else      rhsi = rhsi + (vc0 * dv0 - vcb * dvb) * i_dl + (vla * rva - vl0 * rv0) * i_dl;
+    }
+    vold = vold + rhsi * mask * d.dt;
+    if (d.has_nudg) {
+        const double i__hh = i__h;
+        double vfor = FNUD_(ipnt, ilay, IV);
+        if (d.has_stress) {
+            const double ek = 0.5 * (T3_(d.tt3d, ipnt, IO, ilay) + T3_(d.tt3d, cb, IO, ilay))
+                              * i_r1 * d.invf * i__hh * ramp;
+            vfor = XDIR ? vfor + ek : vfor - ek;
+        }
+        if (d.has_tide) vfor = vfor + ramp * TIDE_(1, ipnt, IV) * cos(TIDE_(2, ipnt, IV) - d.w_ti * ctim);
+        const double ng = NUDG_(ipnt, IV);
+        vold = vfor * ng + vold * (1.0 - ng);
+    }
+    LL(vel, ipnt, ilay) = vold;
+    if (d.rgld < 0.5)
+        LL(hp, ipnt, ilay) = 0.5 * (vold + fabs(vold)) * (hcen - 0.16667 * LL(d2h, cb, ilay))
+                           + 0.5 * (vold - fabs(vold)) * (hcen - 0.16667 * LL(d2h, ipnt, ilay));
+    if (copy_hist) {
+        const double m2 = LL(dm[1], ipnt, ilay), m3 = LL(dm[2], ipnt, ilay);
+        LL(dm[0], ipnt, ilay) = m2;
+        LL(dm[1], ipnt, ilay) = m3;
+        LL(dm[2], ipnt, ilay) = dmd4;
+    } else {
+        LL(dm[0], ipnt, ilay) = dmd4;          // host rotates (dm0,dm1,dm2) <- (dm1,dm2,dm0)
+    }
+}
+
+// ---- distribute_stress, private_mod.f95:1921-2149 -----------------------------------
+// (a) layer fractions layt/layb/layu, cells 0..ndeg (the sentinel included, :1948,1972,1994)
+__global__ __launch_bounds__(BEOM_BLOCK) void k_stress_fractions(DevView d, int wind, int bot, int top) {
+    const int ipnt = blockIdx.x * BEOM_BLOCK + threadIdx.x;     // 0..ndeg
+    if (ipnt > d.ndeg) return;
+    const int nlay = d.nlay;
+    if (wind || top) {
+        for (int pass = 0; pass < 2; ++pass) {
+            if (pass == 0 && !wind) continue;
+            if (pass == 1 && !top) continue;
+            double *lay = pass == 0 ? d.layt : d.layu;
+            if (d.ocrp > 0.5) {
+                for (int ilay = 1; ilay <= nlay; ++ilay) {
+                    double hcum = 0.0, sofar = 0.0;
+                    for (int k = 1; k < ilay; ++k) sofar = sofar + LL(lay, ipnt, k);
+                    sofar = sofar + 0.0;                              // lay(ipnt,ilay) = 0 first (:1949,1995)
+                    for (int k = 1; k <= ilay; ++k) hcum = hcum + fmax(0.0, LL(d.hlay, ipnt, k) - 1.5 * d.hsal);
+                    double t = fmin(hcum, d.hsbl) / d.hsbl - sofar;
+                    LL(lay, ipnt, ilay) = fmax(t, 0.0);
+                }
+            } else {
+                for (int ilay = 1; ilay <= nlay; ++ilay) LL(lay, ipnt, ilay) = (ilay == 1) ? 1.0 : 0.0;
+            }
+        }
+    }
+    if (bot) {
+        if (d.ocrp > 0.5) {
+            for (int ilay = nlay; ilay >= 1; --ilay) {
+                double sofar = 0.0, hcum = 0.0;
+                sofar = sofar + 0.0;                                  // layb(ipnt,ilay) = 0 first (:1973)
+                for (int k = ilay + 1; k <= nlay; ++k) sofar = sofar + LL(d.layb, ipnt, k);
+                for (int k = ilay; k <= nlay; ++k) hcum = hcum + LL(d.hlay, ipnt, k);
+                double t = fmin(hcum, d.hbbl) / d.hbbl - sofar;
+                LL(d.layb, ipnt, ilay) = fmax(t, 0.0);
+            }
+        } else {
+            for (int ilay = 1; ilay <= nlay; ++ilay) LL(d.layb, ipnt, ilay) = (ilay == nlay) ? 1.0 : 0.0;
+        }
+    }
+}
+
+// (b) bottom (pass 0, :2015-2049) / top (pass 1, :2075-2109) stress at u/v points, cells 0..ndeg
+template <class NB>
+__global__ __launch_bounds__(BEOM_BLOCK) void k_stress_tau(DevView d, int pass) {
+    const int ipnt = blockIdx.x * BEOM_BLOCK + threadIdx.x;     // 0..ndeg
+    if (ipnt > d.ndeg) return;
+    const int nlay = d.nlay;
+    int ilay = pass == 0 ? nlay : 1;
+    if (d.ocrp > 0.5) {
+        if (pass == 0) { for (int k = nlay; k >= 1; --k) if (LL(d.hlay, ipnt, k) > 2.0 * d.hsal) { ilay = k; break; } }
+        else           { for (int k = 1; k <= nlay; ++k) if (LL(d.hlay, ipnt, k) > 2.0 * d.hsal) { ilay = k; break; } }
+    }
+    int c1 = 0, c3 = 0, c4 = 0, c5 = 0, c7 = 0, c8 = 0;
+    if (ipnt > 0) {
+        NB nb(d, ipnt);
+        c1 = nb.template get<1>(); c3 = nb.template get<3>(); c4 = nb.template get<4>();
+        c5 = nb.template get<5>(); c7 = nb.template get<7>(); c8 = nb.template get<8>();
+    }
+    const double uu = LL(d.u, ipnt, ilay), vv = LL(d.v, ipnt, ilay);
+    const double vatu = 0.25 * vv + 0.25 * LL(d.v, c3, ilay) + 0.25 * LL(d.v, c4, ilay) + 0.25 * LL(d.v, c5, ilay);
+    const double uatv = 0.25 * uu + 0.25 * LL(d.u, c1, ilay) + 0.25 * LL(d.u, c7, ilay) + 0.25 * LL(d.u, c8, ilay);
+    const double drg = pass == 0 ? d.bdrg : d.tdrg;
+    const double rh = d.rhon[ilay - 1];
+    double *tau = pass == 0 ? d.taub : d.taum;
+    tau[ipnt]        = uu * drg * rh * (d.qdrg * sqrt(uu * uu + vatu * vatu) + 1.0 - d.qdrg);
+    tau[ipnt + d.n1] = vv * drg * rh * (d.qdrg * sqrt(vv * vv + uatv * uatv) + 1.0 - d.qdrg);
+}
+
+// (c) distribute over layers: tb3d/tu3d (:2056-2071, 2116-2133) and tt3d (:2136-2146)
+template <class NB>
+__global__ __launch_bounds__(BEOM_BLOCK) void k_stress_apply(DevView d, int wind, int bot, int top) {
+    const int ipnt = blockIdx.x * BEOM_BLOCK + threadIdx.x + 1;
+    const int ilay = blockIdx.y + 1;
+    if (ipnt > d.ndeg) return;
+    NB nb(d, ipnt);
+    const int c5 = nb.template get<5>(), c7 = nb.template get<7>();
+    if (bot) {
+        T3_(d.tb3d, ipnt, 1, ilay) = d.taub[ipnt] * 0.5 * (LL(d.layb, ipnt, ilay) + LL(d.layb, c5, ilay));
+        T3_(d.tb3d, ipnt, 2, ilay) = d.taub[ipnt + d.n1] * 0.5 * (LL(d.layb, ipnt, ilay) + LL(d.layb, c7, ilay));
+    }
+    if (top) {
+        T3_(d.tu3d, ipnt, 1, ilay) = d.taum[ipnt] * 0.5 * (LL(d.layu, ipnt, ilay) + LL(d.layu, c5, ilay));
+        T3_(d.tu3d, ipnt, 2, ilay) = d.taum[ipnt + d.n1] * 0.5 * (LL(d.layu, ipnt, ilay) + LL(d.layu, c7, ilay));
+    }
+    if (wind) {
+        T3_(d.tt3d, ipnt, 1, ilay) = d.taus[ipnt] * LL(d.layt, ipnt, ilay);
+        T3_(d.tt3d, ipnt, 2, ilay) = d.taus[ipnt + d.n1] * LL(d.layt, ipnt, ilay);
+    }
+}

@@ -191,7 +191,7 @@ def run(exe: str, cwd: str, dump_upto: int = -1, dump_every: int = 0, t_from: in
     if threads:
         env["OMP_NUM_THREADS"] = str(threads)
     env.setdefault("OMP_STACKSIZE", "1G")
-    cmd = "ulimit -s unlimited 2>/dev/null; exec %s" % os.path.abspath(exe)
+    cmd = "ulimit -s unlimited 2>/dev/null || ulimit -s $(ulimit -H -s) 2>/dev/null; exec %s" % os.path.abspath(exe)
     r = subprocess.run(["bash", "-c", cmd], cwd=cwd, capture_output=True, text=True, env=env,
                        timeout=timeout)
     if r.returncode != 0 or "ERROR CODE" in r.stderr:
