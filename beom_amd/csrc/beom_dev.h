@@ -35,39 +35,122 @@ struct DevView {
     double dl, dt, grav, rho0, beta, epsi, gamm, del1, del2, hmin, hsal, bvis, dvis, bdrg, tdrg,
         qdrg, hsbl, hbbl, uadv, ocrp, rgld, invf, w_ti;
     double rhon[BEOM_MAX_LAYERS];
+    // uniform reciprocals, divided once on the host (IEEE division: same bits as on the device)
+    double i_dl, i_gr, i_ns, i_r0, i_r1, i_rn[BEOM_MAX_LAYERS];
     // which optional terms are live (wave-uniform branches)
     int has_hdot, has_tide, has_bodf, has_nudg, has_stress, has_wind, has_hto;
 };
 
-// ---- neighbour lookup -------------------------------------------------------------
+// ---- cell contexts: where a thread is, who its neighbours are, what its masks are ----
 // Slots follow private_mod.f95:28-30: 1=E 2=NE 3=N 4=NW 5=W 6=SW 7=S 8=SE.
-struct NbGather {
-    const int32_t *row;
-    __device__ __forceinline__ NbGather(const DevView &d, int ipnt) : row(d.neig + 8ll * ipnt) {}
-    template <int K> __device__ __forceinline__ int get() const { return row[K - 1]; }
+#define BEOM_BLOCK 256
+
+template <int K> struct NbOff {
+    static constexpr int di = (K == 1 || K == 2 || K == 8) ? 1 : ((K == 4 || K == 5 || K == 6) ? -1 : 0);
+    static constexpr int dj = (K == 2 || K == 3 || K == 4) ? 1 : ((K == 6 || K == 7 || K == 8) ? -1 : 0);
 };
 
-// Closed form for a frame whose interior is entirely wet (every BASELINE config):
-// neighbour (di,dj) of (i,j) is indc0(wx(i+di), wy(j+dj)), the periodic wraps of
-// index_grid_points (private_mod.f95:614-685) acting on the TARGET coordinate.
-// Verified cell by cell against the caller's neig table in beom_create.
-struct NbDense {
+// Any coastline: neighbours and masks come from the caller's tables.
+struct CellGather {
+    int ipnt;
+    const int32_t *row;
+    const DevView *dv;
+    static dim3 grid(const DevView &d, int nz) {
+        return dim3((unsigned)((d.ndeg + BEOM_BLOCK - 1) / BEOM_BLOCK), (unsigned)nz, 1);
+    }
+    __device__ __forceinline__ bool init(const DevView &d) {
+        ipnt = blockIdx.x * BEOM_BLOCK + threadIdx.x + 1;
+        row = d.neig + 8ll * ipnt;
+        dv = &d;
+        return ipnt <= d.ndeg;
+    }
+    template <int K> __device__ __forceinline__ int nb() const { return row[K - 1]; }
+    __device__ __forceinline__ double mk_n() const { return dv->mk_n[ipnt]; }
+    __device__ __forceinline__ double mk_u() const { return dv->mk_u[ipnt]; }
+    __device__ __forceinline__ double mk_v() const { return dv->mk_v[ipnt]; }
+    __device__ __forceinline__ double mkpe() const { return dv->mkpe[ipnt]; }
+    __device__ __forceinline__ double mkpi() const { return dv->mkpi[ipnt]; }
+    template <int K> __device__ __forceinline__ double mk_n_nb(int c) const { return dv->mk_n[c]; }
+    __device__ __forceinline__ int isub() const { return dv->subc[ipnt]; }
+    __device__ __forceinline__ bool wave_is_interior() const { return false; }
+    __device__ __forceinline__ const CellGather &as_interior() const { return *this; }
+};
+
+// Dense frame (interior entirely wet; every BASELINE config).  Closed form of SURVEY
+// App. A: neighbour (di,dj) of (i,j) is indc0(wx(i+di), wy(j+dj)), the periodic wraps of
+// index_grid_points (private_mod.f95:614-685) acting on the TARGET coordinate; masks are
+// the predicates of :701-714 (+ :621,627,649,655,676 when periodic).  Both are verified
+// cell by cell against the caller's tables in beom_create — no table traffic at run time.
+//
+// Launch shape: a 256-thread workgroup covers 64 columns x 4 consecutive rows (one wave
+// per row, so the N/S rows a wave re-reads were just touched by its sibling waves on the
+// same CU).  Block -> tile map is XCD-aware: consecutive workgroups go round-robin to the
+// 8 XCDs (MI355X_MICROARCH.md), so XCD x sweeps its own band of tile rows and the
+// neighbour rows it re-reads stay in ITS L2.
+// INTERIOR = true is the specialisation for waves whose 64 cells all have
+// 2 <= i <= L-2 and 2 <= j <= M-2: every neighbour is a plain offset and every mask is 1
+// (x*1.0 folds exactly), chosen per wave by a scalar test in the kernels.
+#define BEOM_TILE_X 64
+#define BEOM_TILE_Y 4
+
+template <bool INTERIOR>
+struct CellDenseT {
     int i, j, ipnt, L, M, xper, yper;
-    __device__ __forceinline__ NbDense(const DevView &d, int ip)
-        : ipnt(ip), L(d.L), M(d.M), xper(d.xper), yper(d.yper) {
-        unsigned q = (unsigned)(ip - 1) / (unsigned)d.L;
-        j = (int)q + 1;
-        i = ip - (int)q * d.L;            // 1..L
+    static dim3 grid(const DevView &d, int nz) {
+        const int gx = (d.L + BEOM_TILE_X - 1) / BEOM_TILE_X;
+        const int gy = (d.M + BEOM_TILE_Y - 1) / BEOM_TILE_Y;
+        const int rpx = (gy + 7) / 8;
+        return dim3((unsigned)(8 * rpx * gx), (unsigned)nz, 1);
+    }
+    __device__ __forceinline__ bool init(const DevView &d) {
+        L = d.L; M = d.M; xper = d.xper; yper = d.yper;
+        const int gx = (L + BEOM_TILE_X - 1) / BEOM_TILE_X;
+        const int gy = (M + BEOM_TILE_Y - 1) / BEOM_TILE_Y;
+        const int rpx = (gy + 7) / 8;
+        const int b = blockIdx.x;
+        const int xcd = b & 7, k = b >> 3;
+        const int rib = k / gx, ch = k - rib * gx;
+        const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+        j = (xcd * rpx + rib) * BEOM_TILE_Y + wave + 1;
+        i = ch * BEOM_TILE_X + ((int)threadIdx.x & 63) + 1;
+        ipnt = i + (j - 1) * L;
+        return j <= M && i <= L;
+    }
+    // wave-uniform: do all 64 cells of this wave satisfy 2 <= i <= L-2, 2 <= j <= M-2 ?
+    __device__ __forceinline__ bool wave_is_interior() const {
+        const int i0 = __builtin_amdgcn_readfirstlane(i - ((int)threadIdx.x & 63));   // first column of the wave
+        return i0 >= 2 && i0 + BEOM_TILE_X - 1 <= L - 2 && j >= 2 && j <= M - 2;
+    }
+    __device__ __forceinline__ CellDenseT<true> as_interior() const {
+        CellDenseT<true> r; r.i = i; r.j = j; r.ipnt = ipnt; r.L = L; r.M = M; r.xper = xper; r.yper = yper;
+        return r;
     }
     __device__ __forceinline__ int at(int a, int b) const {
-        // a in 0..L+1, b in 0..M+1
         if (xper) { if (a == 0) a = L - 1; else if (a == L) a = 1; }
         if (yper) { if (b == 0) b = M - 1; else if (b == M) b = 1; }
         return (a >= 1 && a <= L && b >= 1 && b <= M) ? (a + (b - 1) * L) : 0;
     }
-    template <int K> __device__ __forceinline__ int get() const {
-        constexpr int di = (K == 1 || K == 2 || K == 8) ? 1 : ((K == 4 || K == 5 || K == 6) ? -1 : 0);
-        constexpr int dj = (K == 2 || K == 3 || K == 4) ? 1 : ((K == 6 || K == 7 || K == 8) ? -1 : 0);
+    template <int K> __device__ __forceinline__ int nb() const {
+        constexpr int di = NbOff<K>::di, dj = NbOff<K>::dj;
+        if (INTERIOR) return ipnt + di + dj * L;
         return at(i + di, j + dj);
     }
+    __device__ __forceinline__ static double f(bool c) { return c ? 1.0 : 0.0; }
+    __device__ __forceinline__ double mk_n_ij(int a, int b) const { return f(a >= 1 && a <= L - 1 && b >= 1 && b <= M - 1); }
+    __device__ __forceinline__ double mk_n() const { return INTERIOR ? 1.0 : mk_n_ij(i, j); }
+    __device__ __forceinline__ double mk_u() const { return INTERIOR ? 1.0 : f(j <= M - 1 && i <= L - 1 && (i >= 2 || xper)); }
+    __device__ __forceinline__ double mk_v() const { return INTERIOR ? 1.0 : f(i <= L - 1 && j <= M - 1 && (j >= 2 || yper)); }
+    __device__ __forceinline__ double mkpe() const {
+        return INTERIOR ? 1.0 : f(i <= L - 1 && j <= M - 1 && (i >= 2 || xper) && (j >= 2 || yper));
+    }
+    __device__ __forceinline__ double mkpi() const { return 1.0; }
+    template <int K> __device__ __forceinline__ double mk_n_nb(int c) const {
+        if (INTERIOR) return 1.0;
+        int a = i + NbOff<K>::di, b = j + NbOff<K>::dj;
+        if (xper) { if (a == 0) a = L - 1; else if (a == L) a = 1; }
+        if (yper) { if (b == 0) b = M - 1; else if (b == M) b = 1; }
+        return mk_n_ij(a, b);
+    }
+    __device__ __forceinline__ int isub() const { return i; }
 };
+using CellDense = CellDenseT<false>;

@@ -13,7 +13,6 @@
 #include <vector>
 
 #include "beom_kernels.h"
-#include "beom_dense.h"
 
 namespace {
 
@@ -45,7 +44,7 @@ struct beom_engine {
     bool dense = false;
     std::vector<void *> allocs;
     // geometry of the launches
-    dim3 grid_cells, grid_cells_layers, grid_cells0;
+    dim3 grid_cells0, grid_cells_layers_flat;
     bool wind = false, bot = false, top = false;
     char last_err[512] = {0};
 };
@@ -88,23 +87,31 @@ struct HostNb {   // host twin of NbDense::at
     }
 };
 
-bool verify_dense(const beom_params &P, int xper, int yper, const int32_t *neig, const int32_t *subc) {
+bool verify_dense(const beom_params &P, int xper, int yper, const int32_t *neig, const int32_t *subc,
+                  const double *mk_u, const double *mk_v, const double *mk_n, const double *mkpe,
+                  const double *mkpi) {
     const int L = P.lm + 1, M = P.mm + 1;
     if ((long long)P.ndeg != (long long)L * M) return false;
     const HostNb nb{L, M, xper, yper};
     static const int di[8] = {1, 1, 0, -1, -1, -1, 0, 1};
     static const int dj[8] = {0, 1, 1, 1, 0, -1, -1, -1};
     const long long n1 = (long long)P.ndeg + 1;
-    bool ok = true;
     for (int j = 1; j <= M; ++j) {
         for (int i = 1; i <= L; ++i) {
             const long long ip = i + (long long)(j - 1) * L;
-            if (subc[ip] != i || subc[ip + n1] != j) ok = false;
+            if (subc[ip] != i || subc[ip + n1] != j) return false;
             for (int k = 0; k < 8; ++k)
-                if (neig[k + 8 * ip] != nb.at(i + di[k], j + dj[k])) ok = false;
+                if (neig[k + 8 * ip] != nb.at(i + di[k], j + dj[k])) return false;
+            // mask predicates of CellDense (private_mod.f95:701-714 + periodic :621,627,649,655,676)
+            const bool in = i <= L - 1 && j <= M - 1;
+            const double en = in ? 1.0 : 0.0;
+            const double eu = (in && (i >= 2 || xper)) ? 1.0 : 0.0;
+            const double ev = (in && (j >= 2 || yper)) ? 1.0 : 0.0;
+            const double ep = (in && (i >= 2 || xper) && (j >= 2 || yper)) ? 1.0 : 0.0;
+            if (mk_n[ip] != en || mk_u[ip] != eu || mk_v[ip] != ev || mkpe[ip] != ep || mkpi[ip] != 1.0) return false;
         }
     }
-    return ok;
+    return true;
 }
 
 }  // namespace
@@ -151,13 +158,19 @@ int beom_create(const beom_params *prm, int device, const int32_t *neig, const i
     d.qdrg = prm->qdrg; d.hsbl = prm->hsbl; d.hbbl = prm->hbbl; d.uadv = prm->uadv; d.ocrp = prm->ocrp;
     d.rgld = prm->rgld; d.invf = prm->invf; d.w_ti = prm->w_ti;
     for (int i = 0; i < BEOM_MAX_LAYERS; ++i) d.rhon[i] = prm->rhon[i];
+    d.i_dl = 1.0 / prm->dl;                      // private_mod.f95:1428,1511,1599,2321
+    d.i_gr = 1.0 / prm->grav;                    // :2322
+    d.i_ns = 1.0 / (double)(prm->nsal - 1);      // :2328
+    d.i_r0 = 1.0 / prm->rho0;                    // :1429
+    d.i_r1 = 1.0 / prm->rhon[0];                 // :1430
+    for (int i = 0; i < prm->nlay; ++i) d.i_rn[i] = 1.0 / prm->rhon[i];   // :2329
     // periodicity is encoded only in neig (private_mod.f95:614-685); recover it for the dense form
     d.xper = 0; d.yper = 0;
     E->dense = false;
     if (prm->dense_hint && (long long)prm->ndeg == (long long)d.L * d.M) {
         for (int xp = 0; xp < 2 && !E->dense; ++xp)
             for (int yp = 0; yp < 2 && !E->dense; ++yp)
-                if (verify_dense(*prm, xp, yp, neig, subc)) { E->dense = true; d.xper = xp; d.yper = yp; }
+                if (verify_dense(*prm, xp, yp, neig, subc, mk_u, mk_v, mk_n, mkpe, mkpi)) { E->dense = true; d.xper = xp; d.yper = yp; }
     }
     int rc = 0;
 #define UP(name, src, n) if ((rc = dev_upload(E, &d.name, src, (size_t)(n), errm, errm_len))) { beom_destroy(E); return rc; }
@@ -199,8 +212,7 @@ int beom_create(const beom_params *prm, int device, const int32_t *neig, const i
     }
     const unsigned gx = (unsigned)((prm->ndeg + BEOM_BLOCK - 1) / BEOM_BLOCK);
     const unsigned gx0 = (unsigned)((prm->ndeg + 1 + BEOM_BLOCK - 1) / BEOM_BLOCK);
-    E->grid_cells = dim3(gx, 1, 1);
-    E->grid_cells_layers = dim3(gx, (unsigned)prm->nlay, 1);
+    E->grid_cells_layers_flat = dim3(gx, (unsigned)prm->nlay, 1);
     E->grid_cells0 = dim3(gx0, 1, 1);
     HIP_TRY(hipStreamSynchronize(E->stream));
     *out = E;
@@ -337,49 +349,49 @@ int beom_sync(beom_handle E, char *errm, int errm_len) {
 static inline void rot2(double *(&a)[2]) { double *t = a[0]; a[0] = a[1]; a[1] = t; }
 static inline void rot3(double *(&a)[3]) { double *t = a[0]; a[0] = a[1]; a[1] = a[2]; a[2] = t; }
 
+// LAUNCH(kernel-template-name, extra template args..., nz, args...) picks the cell context.
+#define LAUNCH_CTX(KERNEL_G, KERNEL_D, nz, ...)                                                            \
+    do {                                                                                                  \
+        if (E->dense) hipLaunchKernelGGL(KERNEL_D, CellDense::grid(E->d, (nz)), dim3(BEOM_BLOCK), 0, E->stream, __VA_ARGS__); \
+        else hipLaunchKernelGGL(KERNEL_G, CellGather::grid(E->d, (nz)), dim3(BEOM_BLOCK), 0, E->stream, __VA_ARGS__);         \
+    } while (0)
+
 static void launch_rebuild(beom_engine *E) {
-    if (E->dense) hipLaunchKernelGGL(k_rebuild_fluxes<NbDense>, E->grid_cells_layers, dim3(BEOM_BLOCK), 0, E->stream, E->d);
-    else hipLaunchKernelGGL(k_rebuild_fluxes<NbGather>, E->grid_cells_layers, dim3(BEOM_BLOCK), 0, E->stream, E->d);
+    LAUNCH_CTX(k_rebuild_fluxes<CellGather>, k_rebuild_fluxes<CellDense>, E->d.nlay, E->d);
 }
 static void launch_h(beom_engine *E, double gene, double ramp, double ctim) {
-    // variant 1 couples layers inside a cell → one thread walks nlay..1; variant 0: one launch, layer = blockIdx.y
-    const dim3 g = (E->d.variant == 1) ? E->grid_cells : E->grid_cells_layers;
-    if (E->dense) {
-        if (!launch_dense_h(E->d, E->stream, gene, ramp, ctim))
-            hipLaunchKernelGGL(k_update_h<NbDense>, g, dim3(BEOM_BLOCK), 0, E->stream, E->d, gene, ramp, ctim, 0);
-    } else {
-        hipLaunchKernelGGL(k_update_h<NbGather>, g, dim3(BEOM_BLOCK), 0, E->stream, E->d, gene, ramp, ctim, 0);
-    }
+    // variant 1 couples layers inside a cell -> one thread walks nlay..1; variant 0: layer = blockIdx.y
+    const int nz = (E->d.variant == 1) ? 1 : E->d.nlay;
+    if (E->d.has_nudg) LAUNCH_CTX((k_update_h<CellGather, true>), (k_update_h<CellDense, true>), nz, E->d, gene, ramp, ctim, 0);
+    else LAUNCH_CTX((k_update_h<CellGather, false>), (k_update_h<CellDense, false>), nz, E->d, gene, ramp, ctim, 0);
     rot2(E->d.rs);
 }
-static void launch_mont(beom_engine *E, int ilay) {
-    const dim3 g = ilay ? E->grid_cells : E->grid_cells_layers;
-    if (E->dense) {
-        if (ilay || !launch_dense_mont(E->d, E->stream))
-            hipLaunchKernelGGL(k_update_mont<NbDense>, g, dim3(BEOM_BLOCK), 0, E->stream, E->d, ilay);
-    } else {
-        hipLaunchKernelGGL(k_update_mont<NbGather>, g, dim3(BEOM_BLOCK), 0, E->stream, E->d, ilay);
+template <class CTX>
+static bool launch_mont_all(beom_engine *E) {
+    const dim3 g = CTX::grid(E->d, 1), b(BEOM_BLOCK);
+    switch (E->d.nlay) {
+#define CASE_NL(n) case n: hipLaunchKernelGGL((k_update_mont_all<CTX, n>), g, b, 0, E->stream, E->d); return true;
+        CASE_NL(1) CASE_NL(2) CASE_NL(3) CASE_NL(4) CASE_NL(5) CASE_NL(6) CASE_NL(8)
+#undef CASE_NL
+        default: return false;
     }
 }
-static void launch_visc(beom_engine *E, int ilay) {
-    const dim3 g = ilay ? E->grid_cells : E->grid_cells_layers;
-    if (E->dense) {
-        if (ilay || !launch_dense_visc(E->d, E->stream))
-            hipLaunchKernelGGL(k_update_visc<NbDense>, g, dim3(BEOM_BLOCK), 0, E->stream, E->d, ilay);
-    } else {
-        hipLaunchKernelGGL(k_update_visc<NbGather>, g, dim3(BEOM_BLOCK), 0, E->stream, E->d, ilay);
+static void launch_mont(beom_engine *E, int ilay) {
+    if (ilay == 0) {
+        if (E->dense ? launch_mont_all<CellDense>(E) : launch_mont_all<CellGather>(E)) return;
     }
+    const int nz = ilay ? 1 : E->d.nlay;
+    LAUNCH_CTX(k_update_mont<CellGather>, k_update_mont<CellDense>, nz, E->d, ilay);
+}
+static void launch_visc(beom_engine *E, int ilay) {
+    const int nz = ilay ? 1 : E->d.nlay;
+    LAUNCH_CTX(k_update_visc<CellGather>, k_update_visc<CellDense>, nz, E->d, ilay);
 }
 template <bool XDIR>
 static void launch_uv(beom_engine *E, int ilay, double gene, double ramp, double ctim) {
-    const dim3 g = ilay ? E->grid_cells : E->grid_cells_layers;
+    const int nz = ilay ? 1 : E->d.nlay;
     const int copy_hist = ilay ? 1 : 0;       // a single-layer call cannot rotate shared pointers
-    if (E->dense) {
-        if (ilay || !launch_dense_uv<XDIR>(E->d, E->stream, gene, ramp, ctim))
-            hipLaunchKernelGGL((k_update_uv<NbDense, XDIR>), g, dim3(BEOM_BLOCK), 0, E->stream, E->d, ilay, gene, ramp, ctim, copy_hist);
-    } else {
-        hipLaunchKernelGGL((k_update_uv<NbGather, XDIR>), g, dim3(BEOM_BLOCK), 0, E->stream, E->d, ilay, gene, ramp, ctim, copy_hist);
-    }
+    LAUNCH_CTX((k_update_uv<CellGather, XDIR>), (k_update_uv<CellDense, XDIR>), nz, E->d, ilay, gene, ramp, ctim, copy_hist);
     if (!copy_hist) { if (XDIR) rot3(E->d.dmx); else rot3(E->d.dmy); }
 }
 static void launch_stress(beom_engine *E) {
@@ -388,11 +400,9 @@ static void launch_stress(beom_engine *E) {
     hipLaunchKernelGGL(k_stress_fractions, E->grid_cells0, dim3(BEOM_BLOCK), 0, E->stream, E->d, w, b, t);
     for (int pass = 0; pass < 2; ++pass) {
         if ((pass == 0 && !b) || (pass == 1 && !t)) continue;
-        if (E->dense) hipLaunchKernelGGL(k_stress_tau<NbDense>, E->grid_cells0, dim3(BEOM_BLOCK), 0, E->stream, E->d, pass);
-        else hipLaunchKernelGGL(k_stress_tau<NbGather>, E->grid_cells0, dim3(BEOM_BLOCK), 0, E->stream, E->d, pass);
+        hipLaunchKernelGGL(k_stress_tau, E->grid_cells0, dim3(BEOM_BLOCK), 0, E->stream, E->d, pass);
     }
-    if (E->dense) hipLaunchKernelGGL(k_stress_apply<NbDense>, E->grid_cells_layers, dim3(BEOM_BLOCK), 0, E->stream, E->d, w, b, t);
-    else hipLaunchKernelGGL(k_stress_apply<NbGather>, E->grid_cells_layers, dim3(BEOM_BLOCK), 0, E->stream, E->d, w, b, t);
+    hipLaunchKernelGGL(k_stress_apply, E->grid_cells_layers_flat, dim3(BEOM_BLOCK), 0, E->stream, E->d, w, b, t);
 }
 
 extern "C" {

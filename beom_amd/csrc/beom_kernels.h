@@ -1,15 +1,14 @@
 // beom_kernels.h — the five sweeps of the BEOM time step as HIP kernels (gfx950).
 //
 // One thread = one packed cell of one layer (layer = blockIdx.y + 1 unless the sweep
-// couples layers).  Every kernel is a template over the neighbour lookup (NbGather:
-// any coastline, via the neig table; NbDense: index arithmetic, no table traffic).
+// couples layers).  Every kernel is a template over the cell context of beom_dev.h
+// (CellGather: any coastline, neighbours and masks from the caller's tables; CellDense:
+// index arithmetic + mask predicates, XCD-aware tile order, no table traffic).
 // Arithmetic follows the reference statement by statement and in its operation order
 // (compiled with -ffp-contract=off) so results are bit-identical to the Fortran.
 // HBM-bound FP64 stencils: no MFMA (nothing here is a contraction).
 #pragma once
 #include "beom_dev.h"
-
-#define BEOM_BLOCK 256
 
 #define LL(a, ip, il) (a)[(long long)(ip) + d.n1 * (long long)((il) - 1)]
 #define FNUD_(ip, il, iv) d.fnud[(long long)(ip) + d.n1 * ((long long)((il) - 1) + (long long)d.nlay * ((iv) - 1))]
@@ -29,30 +28,34 @@ __device__ __forceinline__ double powi_dev(double x, int n) {   // REAL**INTEGER
 }
 
 // ---- first_three_timesteps prologue, private_mod.f95:2166-2177 ---------------------
-template <class NB>
-__global__ __launch_bounds__(BEOM_BLOCK) void k_rebuild_fluxes(DevView d) {
-    const int ipnt = blockIdx.x * BEOM_BLOCK + threadIdx.x + 1;
-    const int ilay = blockIdx.y + 1;
-    if (ipnt > d.ndeg) return;
-    NB nb(d, ipnt);
-    const int c5 = nb.template get<5>(), c7 = nb.template get<7>();
+template <class C>
+__device__ __forceinline__ void body_rebuild_fluxes(const C &c, const DevView &d) {
+    const int ipnt = c.ipnt, ilay = blockIdx.y + 1;
+    const int c5 = c.template nb<5>(), c7 = c.template nb<7>();
     const double h0 = LL(d.hlay, ipnt, ilay);
-    LL(d.h_u, ipnt, ilay) = LL(d.u, ipnt, ilay) * (h0 + LL(d.hlay, c5, ilay)) / (1.0 + d.mk_u[ipnt]);
-    LL(d.h_v, ipnt, ilay) = LL(d.v, ipnt, ilay) * (h0 + LL(d.hlay, c7, ilay)) / (1.0 + d.mk_v[ipnt]);
+    LL(d.h_u, ipnt, ilay) = LL(d.u, ipnt, ilay) * (h0 + LL(d.hlay, c5, ilay)) / (1.0 + c.mk_u());
+    LL(d.h_v, ipnt, ilay) = LL(d.v, ipnt, ilay) * (h0 + LL(d.hlay, c7, ilay)) / (1.0 + c.mk_v());
+}
+template <class CTX>
+__global__ __launch_bounds__(BEOM_BLOCK) void k_rebuild_fluxes(DevView d) {
+    CTX c;
+    if (!c.init(d)) return;
+    if (c.wave_is_interior()) body_rebuild_fluxes(c.as_interior(), d);
+    else body_rebuild_fluxes(c, d);
 }
 
 // ---- update_h, private_mod.f95:1593-1646; variant 1 = private_mod3d.f95:1635-1683 ---
 // Layers nlay..1 are walked inside the thread (variant 1 reads hlay(ipnt,3) across layers).
-template <class NB>
-__global__ __launch_bounds__(BEOM_BLOCK) void k_update_h(DevView d, double gene, double ramp,
+// FORCED=false compiles the nudging / tide / private_mod3d epilogue out (keeps cos() and its
+// registers away from the common unforced launch); the host picks by d.has_nudg.
+template <bool FORCED, class C>
+__device__ __forceinline__ void body_update_h(const C &c, const DevView &d, double gene, double ramp,
                                                          double ctim, int copy_hist) {
-    const int ipnt = blockIdx.x * BEOM_BLOCK + threadIdx.x + 1;
-    if (ipnt > d.ndeg) return;
-    NB nb(d, ipnt);
-    const int c1 = nb.template get<1>(), c3 = nb.template get<3>();
-    const double i_dl = 1.0 / d.dl;
-    const double mkn = d.mk_n[ipnt];
-    const double ng = d.has_nudg ? NUDG_(ipnt, 1) : 0.0;
+    const int ipnt = c.ipnt;
+    const int c1 = c.template nb<1>(), c3 = c.template nb<3>();
+    const double i_dl = d.i_dl;
+    const double mkn = c.mk_n();
+    const double ng = FORCED ? NUDG_(ipnt, 1) : 0.0;
     const int ilay_hi = gridDim.y == 1 ? d.nlay : (int)blockIdx.y + 1;
     const int ilay_lo = gridDim.y == 1 ? 1 : (int)blockIdx.y + 1;
     for (int ilay = ilay_hi; ilay >= ilay_lo; --ilay) {
@@ -72,7 +75,7 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_update_h(DevView d, double gene,
         }
         hold = hold + rhsi;
         double hnew = hold;
-        if (d.has_nudg) {
+        if (FORCED) {
             double hfor = FNUD_(ipnt, ilay, 1);
             if (d.has_tide) {
                 const double vecl = (ilay == 1) ? 1.0 : 0.0;
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_update_h(DevView d, double gene,
                 hnew = hfor * ng + (1.0 - ng) * hold;
             } else {
                 const double hfor1 = 0.0, hfor2 = 800.0, hfor3 = 0.0;
-                const int isub = d.subc[ipnt];
+                const int isub = c.isub();
                 const int half = d.lm / 2;
                 const double h3v = (ilay == 3) ? hold : LL(d.hlay, ipnt, 3);
                 double hl = hold;
@@ -107,28 +110,36 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_update_h(DevView d, double gene,
         }
     }
 }
+template <class CTX, bool FORCED>
+__global__ __launch_bounds__(BEOM_BLOCK) void k_update_h(DevView d, double gene, double ramp,
+                                                         double ctim, int copy_hist) {
+    CTX c;
+    if (!c.init(d)) return;
+    if (c.wave_is_interior()) body_update_h<FORCED>(c.as_interior(), d, gene, ramp, ctim, copy_hist);
+    else body_update_h<FORCED>(c, d, gene, ramp, ctim, copy_hist);
+}
 
 // ---- update_mont_rvor_pvor_dive_kine, private_mod.f95:2318-2439 ---------------------
-template <class NB>
-__global__ __launch_bounds__(BEOM_BLOCK) void k_update_mont(DevView d, int ilay_only) {
-    const int ipnt = blockIdx.x * BEOM_BLOCK + threadIdx.x + 1;
+template <class C>
+__device__ __forceinline__ void body_update_mont(const C &c, const DevView &d, int ilay_only) {
+    const int ipnt = c.ipnt;
     const int ilay = ilay_only ? ilay_only : (int)blockIdx.y + 1;
-    if (ipnt > d.ndeg) return;
-    NB nb(d, ipnt);
-    const int c1 = nb.template get<1>(), c3 = nb.template get<3>(), c5 = nb.template get<5>(),
-              c6 = nb.template get<6>(), c7 = nb.template get<7>();
-    const double i_dl = 1.0 / d.dl, i_gr = 1.0 / d.grav;
-    const double i_ns = 1.0 / (double)(d.nsal - 1);
+    const int c1 = c.template nb<1>(), c3 = c.template nb<3>(), c5 = c.template nb<5>(),
+              c6 = c.template nb<6>(), c7 = c.template nb<7>();
+    const double i_dl = d.i_dl, i_gr = d.i_gr, i_ns = d.i_ns;
     const double hs_8 = d.hsal;
     const double u_le = LL(d.u, ipnt, ilay), u_ri = LL(d.u, c1, ilay);
     const double v_bo = LL(d.v, ipnt, ilay), v_to = LL(d.v, c3, ilay);
-    const double mkn = d.mk_n[ipnt];
+    const double mkn = c.mk_n();
     const double h0 = LL(d.hlay, ipnt, ilay);
-    double mpot = h0 + d.hmin * (1.0 - mkn);
-    mpot = powi_dev(d.hsal / mpot, d.nsal - 1);
-    mpot = mpot * (-d.ocrp * i_ns * d.hsal * mkn);
+    double mpot = -0.0;          // ocrp = 0: (finite) * (-(0*i_ns*hsal*mk_n)) is -0 exactly
+    if (d.ocrp != 0.0) {
+        mpot = h0 + d.hmin * (1.0 - mkn);
+        mpot = powi_dev(d.hsal / mpot, d.nsal - 1);
+        mpot = mpot * (-d.ocrp * i_ns * d.hsal * mkn);
+    }
     mpot = mpot - (d.has_hto ? d.h_to[ipnt] : 0.0);
-    const double i_rn = 1.0 / d.rhon[ilay - 1];
+    const double i_rn = d.i_rn[ilay - 1];
     for (int i = 1; i <= ilay - 1; ++i)
         mpot = mpot - (d.rhon[ilay - 1] - d.rhon[i - 1]) * i_rn * LL(d.hlay, ipnt, i);
     if (d.rgld < 0.5) {
@@ -138,11 +149,12 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_update_mont(DevView d, int ilay_
     }
     LL(d.mont, ipnt, ilay) = mpot + 0.25 * d.uadv * i_gr
                                   * (u_ri * u_ri + u_le * u_le + v_to * v_to + v_bo * v_bo);
-    const double rv = (v_bo - LL(d.v, c5, ilay) - u_le + LL(d.u, c7, ilay)) * i_dl * d.mkpe[ipnt];
+    const double rv = (v_bo - LL(d.v, c5, ilay) - u_le + LL(d.u, c7, ilay)) * i_dl * c.mkpe();
     LL(d.rvor, ipnt, ilay) = rv;
     const double hE = LL(d.hlay, c1, ilay), hW = LL(d.hlay, c5, ilay),
                  hN = LL(d.hlay, c3, ilay), hS = LL(d.hlay, c7, ilay);
-    const double mk1 = d.mk_n[c1], mk3 = d.mk_n[c3], mk5 = d.mk_n[c5], mk6 = d.mk_n[c6], mk7 = d.mk_n[c7];
+    const double mk1 = c.template mk_n_nb<1>(c1), mk3 = c.template mk_n_nb<3>(c3), mk5 = c.template mk_n_nb<5>(c5),
+                 mk6 = c.template mk_n_nb<6>(c6), mk7 = c.template mk_n_nb<7>(c7);
     double d2x = (hE + hW - h0 * 2.0) * mk1 * mk5 * mkn;
     double d2y = (hN + hS - h0 * 2.0) * mk3 * mk7 * mkn;
     if (d.ocrp > 0.5) {
@@ -152,19 +164,90 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_update_mont(DevView d, int ilay_
     LL(d.d2hx, ipnt, ilay) = d2x;
     LL(d.d2hy, ipnt, ilay) = d2y;
     const double have = h0 + hW + LL(d.hlay, c6, ilay) + hS;
-    LL(d.pvor, ipnt, ilay) = (d.fcor[ipnt] + rv * d.uadv) * d.mkpi[ipnt] * (mkn + mk5 + mk6 + mk7) / have;
+    LL(d.pvor, ipnt, ilay) = (d.fcor[ipnt] + rv * d.uadv) * c.mkpi() * (mkn + mk5 + mk6 + mk7) / have;
     LL(d.dive, ipnt, ilay) = (u_ri - u_le + v_to - v_bo) * i_dl;
+}
+template <class CTX>
+__global__ __launch_bounds__(BEOM_BLOCK) void k_update_mont(DevView d, int ilay_only) {
+    CTX c;
+    if (!c.init(d)) return;
+    if (c.wave_is_interior()) body_update_mont(c.as_interior(), d, ilay_only);
+    else body_update_mont(c, d, ilay_only);
+}
+
+// Same sweep, all NL layers of a cell in one thread: the column hlay(ipnt,1:nlay), the
+// per-cell statics (fcor, h_th, masks) and the neighbour indices are fetched once instead
+// of once per layer (the per-layer form moves ~2.4x the algorithmic bytes at nlay = 4).
+// Operation order per layer is unchanged, so results are bit-identical to k_update_mont.
+template <int NL, class C>
+__device__ __forceinline__ void body_update_mont_all(const C &c, const DevView &d) {
+    const int ipnt = c.ipnt;
+    const int c1 = c.template nb<1>(), c3 = c.template nb<3>(), c5 = c.template nb<5>(),
+              c6 = c.template nb<6>(), c7 = c.template nb<7>();
+    const double i_dl = d.i_dl, i_gr = d.i_gr, i_ns = d.i_ns;
+    const double hs_8 = d.hsal;
+    const double mkn = c.mk_n(), mkpe = c.mkpe(), mkpi = c.mkpi();
+    const double mk1 = c.template mk_n_nb<1>(c1), mk3 = c.template mk_n_nb<3>(c3), mk5 = c.template mk_n_nb<5>(c5),
+                 mk6 = c.template mk_n_nb<6>(c6), mk7 = c.template mk_n_nb<7>(c7);
+    const double fcor = d.fcor[ipnt], h_th = d.h_th[ipnt];
+    const double h_to = d.has_hto ? d.h_to[ipnt] : 0.0;
+    double h[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) h[l] = LL(d.hlay, ipnt, l + 1);
+    double hcol = 0.0;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) hcol = hcol + h[l];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        const int ilay = l + 1;
+        const double u_le = LL(d.u, ipnt, ilay), u_ri = LL(d.u, c1, ilay);
+        const double v_bo = LL(d.v, ipnt, ilay), v_to = LL(d.v, c3, ilay);
+        const double h0 = h[l];
+        double mpot = -0.0;
+        if (d.ocrp != 0.0) {
+            mpot = h0 + d.hmin * (1.0 - mkn);
+            mpot = powi_dev(d.hsal / mpot, d.nsal - 1);
+            mpot = mpot * (-d.ocrp * i_ns * d.hsal * mkn);
+        }
+        mpot = mpot - h_to;
+        const double i_rn = d.i_rn[l];
+#pragma unroll
+        for (int i = 0; i < l; ++i) mpot = mpot - (d.rhon[l] - d.rhon[i]) * i_rn * h[i];
+        if (d.rgld < 0.5) mpot = hcol - h_th + mpot;
+        LL(d.mont, ipnt, ilay) = mpot + 0.25 * d.uadv * i_gr
+                                      * (u_ri * u_ri + u_le * u_le + v_to * v_to + v_bo * v_bo);
+        const double rv = (v_bo - LL(d.v, c5, ilay) - u_le + LL(d.u, c7, ilay)) * i_dl * mkpe;
+        LL(d.rvor, ipnt, ilay) = rv;
+        const double hE = LL(d.hlay, c1, ilay), hW = LL(d.hlay, c5, ilay),
+                     hN = LL(d.hlay, c3, ilay), hS = LL(d.hlay, c7, ilay);
+        double d2x = (hE + hW - h0 * 2.0) * mk1 * mk5 * mkn;
+        double d2y = (hN + hS - h0 * 2.0) * mk3 * mk7 * mkn;
+        if (d.ocrp > 0.5) {
+            if (hE < 2.0 * hs_8 || hW < 2.0 * hs_8 || h0 < 2.0 * hs_8) d2x = 0.0;
+            if (hN < 2.0 * hs_8 || hS < 2.0 * hs_8 || h0 < 2.0 * hs_8) d2y = 0.0;
+        }
+        LL(d.d2hx, ipnt, ilay) = d2x;
+        LL(d.d2hy, ipnt, ilay) = d2y;
+        const double have = h0 + hW + LL(d.hlay, c6, ilay) + hS;
+        LL(d.pvor, ipnt, ilay) = (fcor + rv * d.uadv) * mkpi * (mkn + mk5 + mk6 + mk7) / have;
+        LL(d.dive, ipnt, ilay) = (u_ri - u_le + v_to - v_bo) * i_dl;
+    }
+}
+template <class CTX, int NL>
+__global__ __launch_bounds__(BEOM_BLOCK) void k_update_mont_all(DevView d) {
+    CTX c;
+    if (!c.init(d)) return;
+    if (c.wave_is_interior()) body_update_mont_all<NL>(c.as_interior(), d);
+    else body_update_mont_all<NL>(c, d);
 }
 
 // ---- update_viscosity (Leith part), private_mod.f95:2441-2502 -----------------------
-template <class NB>
-__global__ __launch_bounds__(BEOM_BLOCK) void k_update_visc(DevView d, int ilay_only) {
-    const int ipnt = blockIdx.x * BEOM_BLOCK + threadIdx.x + 1;
+template <class C>
+__device__ __forceinline__ void body_update_visc(const C &c, const DevView &d, int ilay_only) {
+    const int ipnt = c.ipnt;
     const int ilay = ilay_only ? ilay_only : (int)blockIdx.y + 1;
-    if (ipnt > d.ndeg) return;
-    NB nb(d, ipnt);
-    const int c1 = nb.template get<1>(), c2 = nb.template get<2>(), c3 = nb.template get<3>(),
-              c5 = nb.template get<5>(), c6 = nb.template get<6>(), c7 = nb.template get<7>();
+    const int c1 = c.template nb<1>(), c2 = c.template nb<2>(), c3 = c.template nb<3>(),
+              c5 = c.template nb<5>(), c6 = c.template nb<6>(), c7 = c.template nb<7>();
     const double r_bl = LL(d.rvor, ipnt, ilay), r_br = LL(d.rvor, c1, ilay), r_tr = LL(d.rvor, c2, ilay),
                  r_tl = LL(d.rvor, c3, ilay), rbll = LL(d.rvor, c5, ilay), rbbl = LL(d.rvor, c7, ilay);
     const double d_cc = LL(d.dive, ipnt, ilay), d_ri = LL(d.dive, c1, ilay), d_to = LL(d.dive, c3, ilay),
@@ -180,21 +263,25 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_update_visc(DevView d, int ilay_
              + (d_to - d_cc) * (d_to - d_cc) + (d_cc - d_bo) * (d_cc - d_bo);
     LL(d.v_cc, ipnt, ilay) = sqrt(b) * d.dvis * d.dl * d.dl + d.bvis;
 }
+template <class CTX>
+__global__ __launch_bounds__(BEOM_BLOCK) void k_update_visc(DevView d, int ilay_only) {
+    CTX c;
+    if (!c.init(d)) return;
+    if (c.wave_is_interior()) body_update_visc(c.as_interior(), d, ilay_only);
+    else body_update_visc(c, d, ilay_only);
+}
 
 // ---- update_u (XDIR=true, private_mod.f95:1422-1503) and update_v (XDIR=false,
 //      :1505-1591).  The two routines are mirror images: W<->S, N<->E, NW<->SE. -------
-template <class NB, bool XDIR>
-__global__ __launch_bounds__(BEOM_BLOCK) void k_update_uv(DevView d, int ilay_only, double gene,
+template <bool XDIR, class C>
+__device__ __forceinline__ void body_update_uv(const C &c, const DevView &d, int ilay_only, double gene,
                                                           double ramp, double ctim, int copy_hist) {
-    const int ipnt = blockIdx.x * BEOM_BLOCK + threadIdx.x + 1;
+    const int ipnt = c.ipnt;
     const int ilay = ilay_only ? ilay_only : (int)blockIdx.y + 1;
-    if (ipnt > d.ndeg) return;
-    NB nb(d, ipnt);
     // u: cb = W(5), ca = N(3), cd = NW(4);   v: cb = S(7), ca = E(1), cd = SE(8)
-    const int cb = XDIR ? nb.template get<5>() : nb.template get<7>();
-    const int ca = XDIR ? nb.template get<3>() : nb.template get<1>();
-    const int cd = XDIR ? nb.template get<4>() : nb.template get<8>();
-    const double *mk = XDIR ? d.mk_u : d.mk_v;
+    const int cb = XDIR ? c.template nb<5>() : c.template nb<7>();
+    const int ca = XDIR ? c.template nb<3>() : c.template nb<1>();
+    const int cd = XDIR ? c.template nb<4>() : c.template nb<8>();
     double *vel = XDIR ? d.u : d.v;
     const double *hq = XDIR ? d.h_v : d.h_u;       // the transport of the OTHER component
     double *hp = XDIR ? d.h_u : d.h_v;
@@ -203,11 +290,10 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_update_uv(DevView d, int ilay_on
     constexpr int IV = XDIR ? 2 : 3;               // ix_u / ix_v
     constexpr int ID = XDIR ? 1 : 2;               // stress component of this direction
     constexpr int IO = XDIR ? 2 : 1;               // the other one (Ekman term of ufor/vfor)
-    const double i_dl = 1.0 / d.dl, i_r0 = 1.0 / d.rho0, i_r1 = 1.0 / d.rhon[0];
-    const double mask = mk[ipnt];
+    const double i_dl = d.i_dl, i_r0 = d.i_r0, i_r1 = d.i_r1;
+    const double mask = XDIR ? c.mk_u() : c.mk_v();
     const double hcen = XDIR ? (LL(d.hlay, cb, ilay) + LL(d.hlay, ipnt, ilay)) / (1.0 + mask)
                              : (LL(d.hlay, ipnt, ilay) + LL(d.hlay, cb, ilay)) / (1.0 + mask);
-    const double i__h = 1.0 / (hcen + 1.0 - mask);
     double vold = LL(vel, ipnt, ilay);
     const double dmd4 = (LL(d.mont, cb, ilay) - LL(d.mont, ipnt, ilay)) * i_dl * d.grav * mask;
     const double pv0 = LL(d.pvor, ipnt, ilay), pva = LL(d.pvor, ca, ilay);
@@ -216,6 +302,7 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_update_uv(DevView d, int ilay_on
     if (XDIR) rhsi = rhsi + 0.25 * pv0 * (q0 + qb) + 0.25 * pva * (qa + qd);
     else      rhsi = rhsi - 0.25 * pv0 * (q0 + qb) - 0.25 * pva * (qa + qd);
     if (d.has_stress) {
+        const double i__h = 1.0 / (hcen + 1.0 - mask);
         const double tauw = 0.5 * (T3_(d.tt3d, cb, ID, ilay) + T3_(d.tt3d, ipnt, ID, ilay)) * ramp;
         rhsi = rhsi + tauw * i_r0 * i__h;
         rhsi = rhsi - T3_(d.tb3d, ipnt, ID, ilay) * i_r0 * i__h;
@@ -236,7 +323,7 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_update_uv(DevView d, int ilay_on
     }
     vold = vold + rhsi * mask * d.dt;
     if (d.has_nudg) {
-        const double i__hh = i__h;
+        const double i__hh = 1.0 / (hcen + 1.0 - mask);
         double vfor = FNUD_(ipnt, ilay, IV);
         if (d.has_stress) {
             const double ek = 0.5 * (T3_(d.tt3d, ipnt, IO, ilay) + T3_(d.tt3d, cb, IO, ilay))
@@ -259,6 +346,14 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_update_uv(DevView d, int ilay_on
     } else {
         LL(dm[0], ipnt, ilay) = dmd4;          // host rotates (dm0,dm1,dm2) <- (dm1,dm2,dm0)
     }
+}
+template <class CTX, bool XDIR>
+__global__ __launch_bounds__(BEOM_BLOCK) void k_update_uv(DevView d, int ilay_only, double gene,
+                                                          double ramp, double ctim, int copy_hist) {
+    CTX c;
+    if (!c.init(d)) return;
+    if (c.wave_is_interior()) body_update_uv<XDIR>(c.as_interior(), d, ilay_only, gene, ramp, ctim, copy_hist);
+    else body_update_uv<XDIR>(c, d, ilay_only, gene, ramp, ctim, copy_hist);
 }
 
 // ---- distribute_stress, private_mod.f95:1921-2149 -----------------------------------
@@ -303,7 +398,7 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_stress_fractions(DevView d, int 
 }
 
 // (b) bottom (pass 0, :2015-2049) / top (pass 1, :2075-2109) stress at u/v points, cells 0..ndeg
-template <class NB>
+//     (runs once per n_3d steps and needs the sentinel cell: always via the neig table)
 __global__ __launch_bounds__(BEOM_BLOCK) void k_stress_tau(DevView d, int pass) {
     const int ipnt = blockIdx.x * BEOM_BLOCK + threadIdx.x;     // 0..ndeg
     if (ipnt > d.ndeg) return;
@@ -315,9 +410,8 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_stress_tau(DevView d, int pass) 
     }
     int c1 = 0, c3 = 0, c4 = 0, c5 = 0, c7 = 0, c8 = 0;
     if (ipnt > 0) {
-        NB nb(d, ipnt);
-        c1 = nb.template get<1>(); c3 = nb.template get<3>(); c4 = nb.template get<4>();
-        c5 = nb.template get<5>(); c7 = nb.template get<7>(); c8 = nb.template get<8>();
+        const int32_t *row = d.neig + 8ll * ipnt;
+        c1 = row[0]; c3 = row[2]; c4 = row[3]; c5 = row[4]; c7 = row[6]; c8 = row[7];
     }
     const double uu = LL(d.u, ipnt, ilay), vv = LL(d.v, ipnt, ilay);
     const double vatu = 0.25 * vv + 0.25 * LL(d.v, c3, ilay) + 0.25 * LL(d.v, c4, ilay) + 0.25 * LL(d.v, c5, ilay);
@@ -330,13 +424,11 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_stress_tau(DevView d, int pass) 
 }
 
 // (c) distribute over layers: tb3d/tu3d (:2056-2071, 2116-2133) and tt3d (:2136-2146)
-template <class NB>
 __global__ __launch_bounds__(BEOM_BLOCK) void k_stress_apply(DevView d, int wind, int bot, int top) {
     const int ipnt = blockIdx.x * BEOM_BLOCK + threadIdx.x + 1;
     const int ilay = blockIdx.y + 1;
     if (ipnt > d.ndeg) return;
-    NB nb(d, ipnt);
-    const int c5 = nb.template get<5>(), c7 = nb.template get<7>();
+    const int c5 = d.neig[8ll * ipnt + 4], c7 = d.neig[8ll * ipnt + 6];
     if (bot) {
         T3_(d.tb3d, ipnt, 1, ilay) = d.taub[ipnt] * 0.5 * (LL(d.layb, ipnt, ilay) + LL(d.layb, c5, ilay));
         T3_(d.tb3d, ipnt, 2, ilay) = d.taub[ipnt + d.n1] * 0.5 * (LL(d.layb, ipnt, ilay) + LL(d.layb, c7, ilay));

@@ -22,11 +22,9 @@ def run(sample: str = "1024x1024x4") -> dict:
     from beom_amd import inputs
     import build_ref_baseline as brb
     lm, mm, nlay = (int(x) for x in sample.split("x"))
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    import oracle_lib
+    cores = oracle_lib.host_cores()
+    cores = int(os.environ.get("BEOM_CPU_BASELINE_THREADS", cores))
     nsteps = brb.NSTEPS
     p = brb.params(lm, mm, nlay, nsteps)
     _, files = inputs.case_headline(lm, mm, nlay)

@@ -32,9 +32,27 @@ def build():
 _lib = None
 
 
+def host_cores() -> int:
+    """CPUs this process may really use: cgroup quota if any, else the affinity mask."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(per) + 0.5)))
+    except Exception:
+        pass
+    return n
+
+
 def load():
     global _lib
     if _lib is None:
+        # small fixtures: a big OpenMP team only adds barrier cost (256-way on the GPU box)
+        os.environ.setdefault("OMP_NUM_THREADS", str(min(8, host_cores())))
         if not os.path.exists(LIB):
             build()
         _lib = C.CDLL(LIB)

@@ -141,3 +141,39 @@ def test_unsupported_options_fail_loudly():
     f.p = f.p.replace(svis="0.", rgld="1.")
     with pytest.raises(capi.BeomError):
         capi.Engine(f)
+
+
+def _big_cases():
+    from beom_amd import inputs as I
+    return {
+        "closed_3l": lambda: I.case_headline(150, 37, 3),
+        "soliton_xper": lambda: I.case_soliton(lm=141, mm=23, dt_s=5.0),
+        "jet_xyper_2l": lambda: I.case_unstable_jet(lm=131, mm=151, nlay=2, dt_s=1.5),
+        "sill_ocrp_nudg_4l": lambda: I.case_sill_exchange3d(lm=133, mm=41, nlay=4, dt_s=0.01, npts=5,
+                                                            sill_halfwidth=6.0),
+        "stommel_wind_drag": lambda: I.case_stommel(lm=200, mm=30, dl=50.0e3, dt_s=0.2),
+    }
+
+
+@pytest.mark.parametrize("case", ["closed_3l", "soliton_xper", "jet_xyper_2l", "sill_ocrp_nudg_4l",
+                                  "stommel_wind_drag"])
+def test_dense_interior_waves_match_oracle_and_gather(case):
+    """Grids wide enough (L >= 130) that most waves take the INTERIOR specialisation of
+    CellDenseT; the dense path, the gather path and the oracle must agree bitwise."""
+    from beom_amd.grid import read_input_data
+    p, files = _big_cases()[case]()
+    f = read_input_data(p, files=files)
+    e_dense = capi.Engine(f, dense_hint=1)
+    e_gath = capi.Engine(f, dense_hint=0)
+    assert e_dense.is_dense and not e_gath.is_dense
+    o = oracle_lib.Oracle(f)
+    for x in (e_dense, e_gath, o):
+        x.step(1, 12)
+    sd, sg = e_dense.download(), e_gath.download()
+    for k in STATE:
+        assert same(sd[k], o.state()[k]), (case, "dense", k, maxrel(sd[k], o.state()[k]))
+        assert same(sg[k], o.state()[k]), (case, "gather", k)
+    scd, scg = e_dense.download_scratch(), e_gath.download_scratch()
+    for k in SCRATCH:
+        assert same(scd[k], scg[k]), (case, k)
+    e_dense.close(); e_gath.close()
