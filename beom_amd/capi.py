@@ -16,16 +16,16 @@ from .grid import Fields
 from .params import Params
 
 BEOM_MAX_LAYERS = 16
-BEOM_ABI_VERSION = 1
+BEOM_ABI_VERSION = 2
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libbeom_hip.so")
+LIB_PATH = os.environ.get("BEOM_HIP_LIB", os.path.join(_HERE, "csrc", "libbeom_hip.so"))
 
 
 class BeomParams(C.Structure):
     """struct beom_params of include/beom_hip.h."""
     _fields_ = (
         [(n, C.c_int32) for n in ("abi_version", "lm", "mm", "nlay", "ndeg", "nsal", "variant",
-                                  "flag_nudging", "dense_hint")]
+                                  "flag_nudging", "dense_hint", "slab_row0", "slab_mm")]
         + [(n, C.c_double) for n in ("dl", "dt", "grav", "rho0", "beta", "epsi", "gamm", "del1",
                                      "del2", "hmin", "hsal", "bvis", "dvis", "svis", "bdrg",
                                      "tdrg", "qdrg", "hsbl", "hbbl", "g_fb", "uadv", "ocrp",
@@ -35,7 +35,7 @@ class BeomParams(C.Structure):
 
 
 def make_params_struct(p: Params, f: Optional[Fields] = None, variant: int = 0,
-                       dense_hint: int = 1) -> BeomParams:
+                       dense_hint: int = 1, slab_row0: int = 0, slab_mm: int = 0) -> BeomParams:
     s = BeomParams()
     s.abi_version = BEOM_ABI_VERSION
     s.lm, s.mm, s.nlay, s.ndeg = p.lm, p.mm, p.nlay, p.ndeg
@@ -43,6 +43,7 @@ def make_params_struct(p: Params, f: Optional[Fields] = None, variant: int = 0,
     s.variant = variant
     s.flag_nudging = int(bool(f.flag_nudging)) if f is not None else 0
     s.dense_hint = dense_hint
+    s.slab_row0, s.slab_mm = slab_row0, slab_mm
     for n in ("dl", "dt", "grav", "rho0", "beta", "epsi", "gamm", "del1", "del2", "hmin", "hsal",
               "bvis", "dvis", "svis", "bdrg", "tdrg", "qdrg", "hsbl", "hbbl", "g_fb", "uadv",
               "ocrp", "rgld", "mcbc"):
@@ -93,6 +94,9 @@ def load(path: Optional[str] = None) -> C.CDLL:
     lib.beom_download_scratch.argtypes = [H] + [dpp] * 6 + [cp, ci]
     lib.beom_step.argtypes = [H, ci, ci, cd, cd, cd, cd, ci, cp, ci]
     lib.beom_sync.argtypes = [H, cp, ci]
+    lib.beom_set_stream.argtypes = [H, C.c_void_p]
+    lib.beom_profile_start.argtypes = [H]
+    lib.beom_profile_stop.argtypes = [H, dpp, C.POINTER(ci), cp, ci]
     lib.beom_update_h.argtypes = [H, cd, cd, cd]
     lib.beom_update_mont_rvor_pvor_dive_kine.argtypes = [H, ci]
     lib.beom_update_viscosity.argtypes = [H, ci]
@@ -108,7 +112,8 @@ def load(path: Optional[str] = None) -> C.CDLL:
                  "beom_download_state", "beom_download_scratch", "beom_step", "beom_sync",
                  "beom_update_h", "beom_update_mont_rvor_pvor_dive_kine", "beom_update_viscosity",
                  "beom_update_u", "beom_update_v", "beom_rebuild_fluxes", "beom_distribute_stress",
-                 "beom_device_field", "beom_is_dense", "beom_profile_steps"):
+                 "beom_device_field", "beom_is_dense", "beom_profile_steps", "beom_set_stream",
+                 "beom_profile_start", "beom_profile_stop"):
         getattr(lib, name).restype = ci
     if lib.beom_abi_version() != BEOM_ABI_VERSION:
         raise RuntimeError("ABI mismatch")
@@ -120,7 +125,8 @@ EXPORTS = ("beom_abi_version", "beom_device_count", "beom_create", "beom_destroy
            "beom_upload_state", "beom_download_state", "beom_download_scratch", "beom_step",
            "beom_sync", "beom_update_h", "beom_update_mont_rvor_pvor_dive_kine",
            "beom_update_viscosity", "beom_update_u", "beom_update_v", "beom_rebuild_fluxes",
-           "beom_distribute_stress", "beom_device_field", "beom_is_dense", "beom_profile_steps")
+           "beom_distribute_stress", "beom_device_field", "beom_is_dense", "beom_profile_steps",
+           "beom_set_stream", "beom_profile_start", "beom_profile_stop")
 
 STATE_NAMES = ("hlay", "u", "v", "h_u", "h_v", "rs_h", "dmdx", "dmdy", "v_cc", "v_ll",
                "tt3d", "tb3d", "tu3d")
@@ -135,11 +141,12 @@ class Engine:
     """One handle = one GPU's copy of the engine state (mirror of the Fortran module)."""
 
     def __init__(self, f: Fields, device: int = 0, variant: int = 0, dense_hint: int = 1,
-                 upload: bool = True):
+                 upload: bool = True, slab_row0: int = 0, slab_mm: int = 0):
         self.lib = load()
         self.f = f
         self.p = f.p
-        self.prm = make_params_struct(f.p, f, variant, dense_hint)
+        self.device = device
+        self.prm = make_params_struct(f.p, f, variant, dense_hint, slab_row0, slab_mm)
         self._err = C.create_string_buffer(ERRLEN + 1)
         self.h = C.c_void_p()
         opt = lambda k: _dp(getattr(f, k)) if f.has.get(k, True) else None
@@ -195,6 +202,36 @@ class Engine:
 
     def sync(self):
         self._check(self.lib.beom_sync(self.h, self._err, ERRLEN))
+
+    def set_stream(self, hip_stream: Optional[int]):
+        """hip_stream: integer handle (e.g. torch.cuda.current_stream().cuda_stream) or None."""
+        self._check(self.lib.beom_set_stream(self.h, C.c_void_p(hip_stream) if hip_stream else None))
+
+    def profile_start(self):
+        self._check(self.lib.beom_profile_start(self.h))
+
+    def profile_stop(self):
+        ms = (C.c_double * 8)()
+        nl = (C.c_int * 8)()
+        self._check(self.lib.beom_profile_stop(self.h, ms, nl, self._err, ERRLEN))
+        return list(ms)[:5], list(nl)[:5]
+
+    def field_tensors(self, names=("hlay", "u", "v", "h_u", "h_v")):
+        """Zero-copy torch views [nlay, ndeg+1] of the device-resident prognostic fields."""
+        import torch
+        out = {}
+        n1 = self.p.ndeg + 1
+        for k in names:
+            ptr, sl, sr, r0 = C.c_void_p(), C.c_int64(), C.c_int64(), C.c_int64()
+            self._check(self.lib.beom_device_field(self.h, k.encode(), C.byref(ptr), C.byref(sl),
+                                                   C.byref(sr), C.byref(r0)))
+            assert sl.value == n1
+
+            class _Iface:
+                __cuda_array_interface__ = {"shape": (self.p.nlay, n1), "typestr": "<f8",
+                                            "data": (ptr.value, False), "version": 3}
+            out[k] = torch.as_tensor(_Iface(), device=torch.device("cuda", self.device))
+        return out
 
     def profile_steps(self, tstp_first: int, nsteps: int, tres: float = 0.0):
         p = self.p

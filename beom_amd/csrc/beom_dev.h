@@ -17,7 +17,8 @@ struct DevView {
     // sizes
     int ndeg, nlay, lm, mm, nsal, variant;
     long long n1;                 // ndeg + 1
-    int L, M, xper, yper;         // dense closed form: L = lm+1, M = mm+1
+    int L, M, xper, yper;         // dense closed form: L = lm+1, M = mm+1 (local rows)
+    int joff, Mg, slab;           // j-slab: local row j is global row j + joff of Mg = mm_global+1 rows
     // static
     const int32_t *neig, *subc;
     const double *mk_u, *mk_v, *mk_n, *mkpe, *mkpi, *fcor, *h_th, *h_to;
@@ -90,12 +91,16 @@ struct CellGather {
 // INTERIOR = true is the specialisation for waves whose 64 cells all have
 // 2 <= i <= L-2 and 2 <= j <= M-2: every neighbour is a plain offset and every mask is 1
 // (x*1.0 folds exactly), chosen per wave by a scalar test in the kernels.
+#ifndef BEOM_TILE_X
 #define BEOM_TILE_X 64
-#define BEOM_TILE_Y 4
+#endif
+#define BEOM_TILE_Y (BEOM_BLOCK / BEOM_TILE_X)
+#define BEOM_TILE_WX (BEOM_TILE_X / 64)
 
 template <bool INTERIOR>
 struct CellDenseT {
     int i, j, ipnt, L, M, xper, yper;
+    int jg, Mg, ywrap;            // global row / row count (masks); y wrap only when not a slab
     static dim3 grid(const DevView &d, int nz) {
         const int gx = (d.L + BEOM_TILE_X - 1) / BEOM_TILE_X;
         const int gy = (d.M + BEOM_TILE_Y - 1) / BEOM_TILE_Y;
@@ -111,23 +116,25 @@ struct CellDenseT {
         const int xcd = b & 7, k = b >> 3;
         const int rib = k / gx, ch = k - rib * gx;
         const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-        j = (xcd * rpx + rib) * BEOM_TILE_Y + wave + 1;
-        i = ch * BEOM_TILE_X + ((int)threadIdx.x & 63) + 1;
+        j = (xcd * rpx + rib) * BEOM_TILE_Y + wave / BEOM_TILE_WX + 1;
+        i = ch * BEOM_TILE_X + (wave % BEOM_TILE_WX) * 64 + ((int)threadIdx.x & 63) + 1;
         ipnt = i + (j - 1) * L;
+        jg = j + d.joff; Mg = d.Mg; ywrap = d.yper && !d.slab;
         return j <= M && i <= L;
     }
     // wave-uniform: do all 64 cells of this wave satisfy 2 <= i <= L-2, 2 <= j <= M-2 ?
     __device__ __forceinline__ bool wave_is_interior() const {
         const int i0 = __builtin_amdgcn_readfirstlane(i - ((int)threadIdx.x & 63));   // first column of the wave
-        return i0 >= 2 && i0 + BEOM_TILE_X - 1 <= L - 2 && j >= 2 && j <= M - 2;
+        return i0 >= 2 && i0 + 63 <= L - 2 && j >= 2 && j <= M - 2 && jg >= 2 && jg <= Mg - 2;
     }
     __device__ __forceinline__ CellDenseT<true> as_interior() const {
         CellDenseT<true> r; r.i = i; r.j = j; r.ipnt = ipnt; r.L = L; r.M = M; r.xper = xper; r.yper = yper;
+        r.jg = jg; r.Mg = Mg; r.ywrap = ywrap;
         return r;
     }
-    __device__ __forceinline__ int at(int a, int b) const {
+    __device__ __forceinline__ int at(int a, int b) const {     // a, b: LOCAL target coordinates
         if (xper) { if (a == 0) a = L - 1; else if (a == L) a = 1; }
-        if (yper) { if (b == 0) b = M - 1; else if (b == M) b = 1; }
+        if (ywrap) { if (b == 0) b = M - 1; else if (b == M) b = 1; }
         return (a >= 1 && a <= L && b >= 1 && b <= M) ? (a + (b - 1) * L) : 0;
     }
     template <int K> __device__ __forceinline__ int nb() const {
@@ -136,20 +143,22 @@ struct CellDenseT {
         return at(i + di, j + dj);
     }
     __device__ __forceinline__ static double f(bool c) { return c ? 1.0 : 0.0; }
-    __device__ __forceinline__ double mk_n_ij(int a, int b) const { return f(a >= 1 && a <= L - 1 && b >= 1 && b <= M - 1); }
-    __device__ __forceinline__ double mk_n() const { return INTERIOR ? 1.0 : mk_n_ij(i, j); }
-    __device__ __forceinline__ double mk_u() const { return INTERIOR ? 1.0 : f(j <= M - 1 && i <= L - 1 && (i >= 2 || xper)); }
-    __device__ __forceinline__ double mk_v() const { return INTERIOR ? 1.0 : f(i <= L - 1 && j <= M - 1 && (j >= 2 || yper)); }
+    // masks are functions of the GLOBAL coordinates (i, jg) on the Mg-row frame
+    __device__ __forceinline__ double mk_n_ij(int a, int bg) const { return f(a >= 1 && a <= L - 1 && bg >= 1 && bg <= Mg - 1); }
+    __device__ __forceinline__ double mk_n() const { return INTERIOR ? 1.0 : mk_n_ij(i, jg); }
+    __device__ __forceinline__ double mk_u() const { return INTERIOR ? 1.0 : f(jg <= Mg - 1 && i <= L - 1 && (i >= 2 || xper)); }
+    __device__ __forceinline__ double mk_v() const { return INTERIOR ? 1.0 : f(i <= L - 1 && jg <= Mg - 1 && (jg >= 2 || yper)); }
     __device__ __forceinline__ double mkpe() const {
-        return INTERIOR ? 1.0 : f(i <= L - 1 && j <= M - 1 && (i >= 2 || xper) && (j >= 2 || yper));
+        return INTERIOR ? 1.0 : f(i <= L - 1 && jg <= Mg - 1 && (i >= 2 || xper) && (jg >= 2 || yper));
     }
     __device__ __forceinline__ double mkpi() const { return 1.0; }
     template <int K> __device__ __forceinline__ double mk_n_nb(int c) const {
         if (INTERIOR) return 1.0;
-        int a = i + NbOff<K>::di, b = j + NbOff<K>::dj;
+        if (c == 0) return 0.0;                                  // sentinel (also: outside a slab's window)
+        int a = i + NbOff<K>::di, bg = jg + NbOff<K>::dj;
         if (xper) { if (a == 0) a = L - 1; else if (a == L) a = 1; }
-        if (yper) { if (b == 0) b = M - 1; else if (b == M) b = 1; }
-        return mk_n_ij(a, b);
+        if (ywrap) { if (bg == 0) bg = Mg - 1; else if (bg == Mg) bg = 1; }
+        return mk_n_ij(a, bg);
     }
     __device__ __forceinline__ int isub() const { return i; }
 };

@@ -39,7 +39,9 @@ void set_err(char *errm, int len, const char *fmt, ...) {
 struct beom_engine {
     beom_params P;
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // stream in use (own_stream unless beom_set_stream)
+    hipStream_t own_stream = nullptr;
+    struct StepTimer *timer = nullptr;  // non-null between beom_profile_start/stop
     DevView d{};
     bool dense = false;
     std::vector<void *> allocs;
@@ -78,36 +80,39 @@ bool any_nonzero(const double *a, size_t n) {
     return false;
 }
 
-struct HostNb {   // host twin of NbDense::at
-    int L, M, xper, yper;
+struct HostNb {   // host twin of CellDenseT::at
+    int L, M, xper, ywrap;
     int at(int a, int b) const {
         if (xper) { if (a == 0) a = L - 1; else if (a == L) a = 1; }
-        if (yper) { if (b == 0) b = M - 1; else if (b == M) b = 1; }
+        if (ywrap) { if (b == 0) b = M - 1; else if (b == M) b = 1; }
         return (a >= 1 && a <= L && b >= 1 && b <= M) ? (a + (b - 1) * L) : 0;
     }
 };
 
-bool verify_dense(const beom_params &P, int xper, int yper, const int32_t *neig, const int32_t *subc,
-                  const double *mk_u, const double *mk_v, const double *mk_n, const double *mkpe,
-                  const double *mkpi) {
-    const int L = P.lm + 1, M = P.mm + 1;
-    if ((long long)P.ndeg != (long long)L * M) return false;
-    const HostNb nb{L, M, xper, yper};
+// SURVEY App. A, generalised to a j-slab window: local rows 1..M are global rows
+// joff+1..joff+M of an Mg-row frame.  Neighbours are local indices (0 outside the window);
+// masks and subc(:,2) are those of the global frame.
+bool verify_dense(int L, int M, int joff, int Mg, int slab, int xper, int yper, long long ndeg,
+                  const int32_t *neig, const int32_t *subc, const double *mk_u, const double *mk_v,
+                  const double *mk_n, const double *mkpe, const double *mkpi) {
+    if (ndeg != (long long)L * M) return false;
+    const HostNb nb{L, M, xper, (yper && !slab) ? 1 : 0};
     static const int di[8] = {1, 1, 0, -1, -1, -1, 0, 1};
     static const int dj[8] = {0, 1, 1, 1, 0, -1, -1, -1};
-    const long long n1 = (long long)P.ndeg + 1;
+    const long long n1 = ndeg + 1;
     for (int j = 1; j <= M; ++j) {
+        const int jg = j + joff;
         for (int i = 1; i <= L; ++i) {
             const long long ip = i + (long long)(j - 1) * L;
-            if (subc[ip] != i || subc[ip + n1] != j) return false;
+            if (subc[ip] != i || subc[ip + n1] != jg) return false;
             for (int k = 0; k < 8; ++k)
                 if (neig[k + 8 * ip] != nb.at(i + di[k], j + dj[k])) return false;
-            // mask predicates of CellDense (private_mod.f95:701-714 + periodic :621,627,649,655,676)
-            const bool in = i <= L - 1 && j <= M - 1;
+            // mask predicates of CellDenseT (private_mod.f95:701-714 + periodic :621,627,649,655,676)
+            const bool in = i <= L - 1 && jg <= Mg - 1;
             const double en = in ? 1.0 : 0.0;
             const double eu = (in && (i >= 2 || xper)) ? 1.0 : 0.0;
-            const double ev = (in && (j >= 2 || yper)) ? 1.0 : 0.0;
-            const double ep = (in && (i >= 2 || xper) && (j >= 2 || yper)) ? 1.0 : 0.0;
+            const double ev = (in && (jg >= 2 || yper)) ? 1.0 : 0.0;
+            const double ep = (in && (i >= 2 || xper) && (jg >= 2 || yper)) ? 1.0 : 0.0;
             if (mk_n[ip] != en || mk_u[ip] != eu || mk_v[ip] != ev || mkpe[ip] != ep || mkpi[ip] != 1.0) return false;
         }
     }
@@ -146,7 +151,8 @@ int beom_create(const beom_params *prm, int device, const int32_t *neig, const i
     beom_engine *E = new beom_engine();
     E->P = *prm;
     E->device = device;
-    HIP_TRY(hipStreamCreateWithFlags(&E->stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&E->own_stream, hipStreamNonBlocking));
+    E->stream = E->own_stream;
     DevView &d = E->d;
     const size_t n1 = (size_t)prm->ndeg + 1, nl = (size_t)prm->nlay;
     d.ndeg = prm->ndeg; d.nlay = prm->nlay; d.lm = prm->lm; d.mm = prm->mm; d.nsal = prm->nsal;
@@ -166,11 +172,19 @@ int beom_create(const beom_params *prm, int device, const int32_t *neig, const i
     for (int i = 0; i < prm->nlay; ++i) d.i_rn[i] = 1.0 / prm->rhon[i];   // :2329
     // periodicity is encoded only in neig (private_mod.f95:614-685); recover it for the dense form
     d.xper = 0; d.yper = 0;
+    d.slab = prm->slab_mm > 0 ? 1 : 0;
+    d.joff = d.slab ? prm->slab_row0 : 0;
+    d.Mg = d.slab ? prm->slab_mm + 1 : d.M;
+    if (d.slab && (d.joff < 0 || d.joff + d.M > d.Mg)) { set_err(errm, errm_len, "beom_create: slab rows outside the global frame"); delete E; return -3; }
     E->dense = false;
     if (prm->dense_hint && (long long)prm->ndeg == (long long)d.L * d.M) {
         for (int xp = 0; xp < 2 && !E->dense; ++xp)
-            for (int yp = 0; yp < 2 && !E->dense; ++yp)
-                if (verify_dense(*prm, xp, yp, neig, subc, mk_u, mk_v, mk_n, mkpe, mkpi)) { E->dense = true; d.xper = xp; d.yper = yp; }
+            for (int yp = 0; yp < 2 && !E->dense; ++yp) {
+                if (d.slab && yp) continue;      // a slab of a y-periodic frame gets its wrap from the exchange, not from neig
+                if (verify_dense(d.L, d.M, d.joff, d.Mg, d.slab, xp, yp, prm->ndeg, neig, subc, mk_u, mk_v, mk_n, mkpe, mkpi)) {
+                    E->dense = true; d.xper = xp; d.yper = yp;
+                }
+            }
     }
     int rc = 0;
 #define UP(name, src, n) if ((rc = dev_upload(E, &d.name, src, (size_t)(n), errm, errm_len))) { beom_destroy(E); return rc; }
@@ -224,7 +238,7 @@ int beom_destroy(beom_handle E) {
     (void)hipSetDevice(E->device);
     if (E->stream) (void)hipStreamSynchronize(E->stream);
     for (void *p : E->allocs) (void)hipFree(p);
-    if (E->stream) (void)hipStreamDestroy(E->stream);
+    if (E->own_stream) (void)hipStreamDestroy(E->own_stream);
     delete E;
     return 0;
 }
@@ -448,7 +462,9 @@ struct StepTimer {        // optional HIP-event bracket around each kernel class
     void end() { hipEvent_t b; (void)hipEventCreate(&b); (void)hipEventRecord(b, st); ev.push_back(b); }
 };
 
-static void one_step(beom_engine *E, int tstp, const StepScalars &s, StepTimer *T) {
+static void one_step(beom_engine *E, int tstp, const StepScalars &s) {
+    StepTimer *T = E->timer;
+    if (T) T->st = E->stream;
     if (s.stress) launch_stress(E);
     if (s.first3) launch_rebuild(E);                               // :2166-2177
     if (T) T->begin(0);
@@ -484,19 +500,25 @@ int beom_step(beom_handle E, int tstp_first, int nsteps, double tres, double dtd
     if (tstp_first < 1 || nsteps < 0 || n_3d < 1) { set_err(errm, errm_len, "beom_step: bad arguments"); return -3; }
     HIP_TRY(hipSetDevice(E->device));
     for (int tstp = tstp_first; tstp < tstp_first + nsteps; ++tstp)
-        one_step(E, tstp, step_scalars(E, tstp, tres, dtd8, dt_r, rsta, n_3d), nullptr);
+        one_step(E, tstp, step_scalars(E, tstp, tres, dtd8, dt_r, rsta, n_3d));
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
-int beom_profile_steps(beom_handle E, int tstp_first, int nsteps, double tres, double dtd8, double dt_r,
-                       double rsta, int n_3d, double *ms, int *launches, char *errm, int errm_len) {
+int beom_profile_start(beom_handle E) {
+    if (!E) return -1;
+    if (E->timer) { for (hipEvent_t ev : E->timer->ev) (void)hipEventDestroy(ev); delete E->timer; }
+    E->timer = new StepTimer();
+    E->timer->st = E->stream;
+    return 0;
+}
+
+int beom_profile_stop(beom_handle E, double *ms, int *launches, char *errm, int errm_len) {
     if (!E || !ms || !launches) { set_err(errm, errm_len, "null argument"); return -1; }
+    if (!E->timer) { set_err(errm, errm_len, "beom_profile_stop without beom_profile_start"); return -3; }
     HIP_TRY(hipSetDevice(E->device));
-    StepTimer T; T.st = E->stream;
-    for (int tstp = tstp_first; tstp < tstp_first + nsteps; ++tstp)
-        one_step(E, tstp, step_scalars(E, tstp, tres, dtd8, dt_r, rsta, n_3d), &T);
     HIP_TRY(hipStreamSynchronize(E->stream));
+    StepTimer &T = *E->timer;
     for (int c = 0; c < 5; ++c) { ms[c] = 0.0; launches[c] = 0; }
     for (size_t k = 0; k < T.cls.size(); ++k) {
         float t = 0.f;
@@ -504,8 +526,25 @@ int beom_profile_steps(beom_handle E, int tstp_first, int nsteps, double tres, d
         ms[T.cls[k]] += (double)t;
         launches[T.cls[k]] += 1;
     }
-    for (hipEvent_t e : T.ev) (void)hipEventDestroy(e);
+    for (hipEvent_t ev : T.ev) (void)hipEventDestroy(ev);
+    delete E->timer;
+    E->timer = nullptr;
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int beom_profile_steps(beom_handle E, int tstp_first, int nsteps, double tres, double dtd8, double dt_r,
+                       double rsta, int n_3d, double *ms, int *launches, char *errm, int errm_len) {
+    int rc = beom_profile_start(E);
+    if (rc) { set_err(errm, errm_len, "null handle"); return rc; }
+    rc = beom_step(E, tstp_first, nsteps, tres, dtd8, dt_r, rsta, n_3d, errm, errm_len);
+    if (rc) return rc;
+    return beom_profile_stop(E, ms, launches, errm, errm_len);
+}
+
+int beom_set_stream(beom_handle E, void *hip_stream) {
+    if (!E) return -1;
+    E->stream = hip_stream ? (hipStream_t)hip_stream : E->own_stream;
     return 0;
 }
 

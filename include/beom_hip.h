@@ -39,7 +39,7 @@ extern "C" {
 #endif
 
 #define BEOM_MAX_LAYERS 16
-#define BEOM_ABI_VERSION 1
+#define BEOM_ABI_VERSION 2
 
 /* Constants of shared_mod.f95:41-99, passed BY VALUE from the host so that the
  * single-precision literals widened to double (grav = 9.8, beta = 0.281105, ...) keep
@@ -53,6 +53,10 @@ typedef struct beom_params {
     int32_t flag_nudging;       /* private_mod.f95:93,868-871                        */
     int32_t dense_hint;         /* 1: let the library verify neig against the dense
                                    closed form and use the fast path */
+    int32_t slab_row0;          /* j-slab of a larger frame (multi-GPU): the
+                                   handle's row 1 is global row slab_row0 + 1 ...        */
+    int32_t slab_mm;            /* ... of a frame with this many rows (global mm);
+                                   0 = the handle holds the whole frame                  */
     double dl, dt;              /* shared_mod.f95:47,84                              */
     double grav, rho0;          /* :89-90                                            */
     double beta, epsi, gamm, del1, del2; /* :91-95                                   */
@@ -125,6 +129,10 @@ int beom_step(beom_handle h, int tstp_first, int nsteps,
 
 int beom_sync(beom_handle h, char *errm, int errm_len);
 
+/* Run all launches of this handle on the caller's HIP stream (e.g. the stream a
+ * ghost-row exchange is enqueued on); NULL restores the handle's own stream. */
+int beom_set_stream(beom_handle h, void *hip_stream);
+
 /* Per-sweep entry points with the reference routines' meaning; used by parity tests.
  * ilay is 1-based as in Fortran; ilay = 0 means "all layers" (one batched launch).
  * The per-step scalars gene/ramp/ctim are module variables in the reference
@@ -144,10 +152,13 @@ int beom_device_field(beom_handle h, const char *name, void **dptr,
                       int64_t *stride_layer, int64_t *stride_row, int64_t *row0_offset);
 /* 1 if the dense fast path is active for this handle, else 0. */
 int beom_is_dense(beom_handle h);
-/* Runs `nsteps` steps starting at tstp_first and returns the elapsed device time of
- * each kernel class, measured with HIP events on the handle's stream:
- * ms[0..4] = update_h, update_mont, update_viscosity, update_u, update_v (sums),
- * launches[0..4] = number of launches in each class. */
+/* Per-kernel device time, measured with HIP events on the handle's stream around every
+ * sweep launched by beom_step between start and stop (no host synchronisation in
+ * between): ms[0..4] = update_h, update_mont, update_viscosity, update_u, update_v
+ * (sums over launches), launches[0..4] = number of launches in each class. */
+int beom_profile_start(beom_handle h);
+int beom_profile_stop(beom_handle h, double *ms, int *launches, char *errm, int errm_len);
+/* = beom_profile_start; beom_step(...); beom_profile_stop. */
 int beom_profile_steps(beom_handle h, int tstp_first, int nsteps,
                        double tres, double dtd8, double dt_r, double rsta, int n_3d,
                        double *ms, int *launches, char *errm, int errm_len);

@@ -177,3 +177,70 @@ def test_dense_interior_waves_match_oracle_and_gather(case):
     for k in SCRATCH:
         assert same(scd[k], scg[k]), (case, k)
     e_dense.close(); e_gath.close()
+
+
+@pytest.mark.parametrize("case,world", [("closed_3l", 2), ("closed_3l", 3), ("sill_ocrp_nudg_4l", 2),
+                                        ("soliton_xper", 2)])
+def test_slabs_on_one_gpu_match_single_domain(case, world):
+    """j-slab windows (beom_params.slab_row0/slab_mm: masks from global coordinates, dense
+    fast path on every slab) stepped side by side on ONE GPU, ghost rows moved with the
+    pack/unpack code of beom_amd.slab and a device copy in place of RCCL: owned rows must
+    equal the single-domain GPU run bit for bit."""
+    import torch
+    from beom_amd import slab
+    from beom_amd.grid import read_input_data
+    p, files = _big_cases()[case]()
+    f = read_input_data(p, files=files)
+    whole = capi.Engine(f)
+    geoms = slab.decompose(p.mm, p.lm, world)
+    runs = []
+    for g in geoms:
+        lf = slab.slice_fields(f, g)
+        e = capi.Engine(lf, slab_row0=g.row0, slab_mm=p.mm)
+        assert e.is_dense
+        e.set_stream(torch.cuda.current_stream().cuda_stream)
+        runs.append(slab.SlabRunner(e, g, p.nlay, dist=None))
+    # the tensors are views of the live device state, not copies
+    t0 = runs[0].t["hlay"]
+    keep = t0[0, 5].item()
+    t0[0, 5] = 12345.0
+    torch.cuda.synchronize()
+    assert runs[0].engine.download(("hlay",))["hlay"][0, 5] == 12345.0
+    t0[0, 5] = keep
+    nsteps = 12
+    for t in range(1, nsteps + 1):
+        for r in runs:
+            r.engine.step(t, 1, sync=False)
+        for r in runs:
+            r.pack_all()
+        for k in range(world - 1):
+            runs[k + 1].recv_s.copy_(runs[k].send_n)
+            runs[k].recv_n.copy_(runs[k + 1].send_s)
+        for r in runs:
+            r.unpack_all()
+    torch.cuda.synchronize()
+    whole.step(1, nsteps)
+    ref = whole.download()
+    for r in runs:
+        g = r.g
+        a, b = 1 + (g.own0 - 1) * g.L, 1 + g.own1 * g.L
+        la, lb = g.local_rows(g.own0, g.own1)
+        st = r.engine.download()
+        for k in STATE:
+            if st[k].ndim == 3 and st[k].shape[-1] in (2, 3) and k in ("rs_h", "dmdx", "dmdy"):
+                assert same(st[k][:, la:lb, :], ref[k][:, a:b, :]), (case, g.rank, k)
+            else:
+                assert same(st[k][..., la:lb], ref[k][..., a:b]), (case, g.rank, k)
+        r.engine.close()
+    whole.close()
+
+
+def test_profile_start_stop_counts_launches():
+    g = Golden("jet_2l_xyper")
+    e = capi.Engine(_fields(g))
+    e.step(1, 4)
+    e.profile_start()
+    e.step(5, 6, sync=False)
+    ms, nl = e.profile_stop()
+    assert nl == [6, 6, 6, 6, 6] and all(m > 0 for m in ms)
+    e.close()
