@@ -66,9 +66,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = max(torch.cuda.device_count(), 1)
+    backend = os.environ.get("BEOM_DIST_BACKEND", "nccl")     # "gloo": rehearsal of N ranks on one GPU
+    if local_rank >= ndev and backend == "nccl":
+        raise SystemExit("bench.py: LOCAL_RANK %d but only %d GPUs visible" % (local_rank, ndev))
+    local_rank = local_rank % ndev
     if world > 1:
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     n_gpus = world
     if a.gpus != world and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (a.gpus, world), file=sys.stderr)
@@ -94,6 +102,7 @@ def main():
     t_setup = time.time() - t0
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -109,7 +118,7 @@ def main():
     t2 = time.perf_counter()
     elapsed = t2 - t1
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 

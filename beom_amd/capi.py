@@ -79,6 +79,13 @@ def load(path: Optional[str] = None) -> C.CDLL:
     if _lib is not None and path is None:
         return _lib
     path = path or LIB_PATH
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64, and if this
+    # library pulls in /opt/rocm's copy first, torch later finds "No HIP GPUs".  Let torch
+    # (when present) load its runtime first; libbeom_hip.so then binds to the same one.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(path):
         raise RuntimeError("HIP engine library %s not built (run __graft_entry__.build()); "
                            "there is no CPU fallback" % path)
