@@ -72,7 +72,7 @@ def case_island(nlay=3):
     cext = np.sqrt(9.8 * h_bo.max())
     dt = 0.5 * dl / cext
     p = make_params(lm, mm, nlay, ndeg, dl, cext, 1.0e-4, [1026.0, 1027.0, 1028.0][:nlay], topl,
-                    12 * dt / 86400.0, 1.0, 6.4 * dt / 86400.0, 2.2 * dt / 86400.0, 5.0, 0.3, 2.5e-3,
+                    12 * dt / 86400.0, 4 * dt / 86400.0, 6.4 * dt / 86400.0, 2.2 * dt / 86400.0, 5.0, 0.3, 2.5e-3,
                     1.0, 10.0, 10.0, 1.0, 1.0, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0,
                     desc="golden: island, wind, quadratic drag, hdot, bodf, ramp, dt3d")
     return p, {"h_bo": h_bo, "init": init, "taus": taus, "hdot": hdot, "bodf": bodf, "fcor": fcor}
@@ -129,7 +129,7 @@ CASES = {
     # name: (builder, reference engine file)
     "stommel_24x16": (lambda: I.case_stommel(lm=24, mm=16, dl=100.0e3, dt_s=0.2), "private_mod.f95"),
     "soliton_31x15_xper": (lambda: I.case_soliton(lm=31, mm=15, dt_s=5.0), "private_mod.f95"),
-    "jet_2l_xyper": (lambda: I.case_unstable_jet(lm=21, mm=27, nlay=2, dt_s=1.5), "private_mod.f95"),
+    "jet_2l_xyper": (lambda: I.case_unstable_jet(lm=21, mm=27, nlay=2, dt_s=1.5, dt_o=0.45), "private_mod.f95"),
     "jet_1l_xyper_stdfb": (lambda: _std_fb(I.case_unstable_jet(lm=21, mm=27, nlay=1, dt_s=1.5)), "private_mod.f95"),
     "sill_2l_ocrp": (lambda: I.case_sill_exchange3d(lm=15, mm=41, nlay=2, dt_s=0.01, npts=5,
                                                     sill_halfwidth=6.0), "private_mod.f95"),
@@ -163,8 +163,9 @@ def generate(name):
         d = refdump.read_step(os.path.join(work, "oracle_step_%06d.bin" % t), p.nlay, p.ndeg)
         for k, a in d.items():
             out["step%d_%s" % (t, k)] = np.asarray(a)
-    for fn in ("grid.bin", "h_0.bin", "eta_.bin", "u___.bin", "v___.bin"):
-        out["file_" + fn.replace(".", "_")] = np.fromfile(os.path.join(work, fn), dtype=np.uint8)
+    for fn in ("grid.bin", "h_0.bin", "eta_.bin", "u___.bin", "v___.bin", "pvor.bin", "mont.bin", "v_cc.bin"):
+        if os.path.exists(os.path.join(work, fn)):
+            out["file_" + fn.replace(".", "_")] = np.fromfile(os.path.join(work, fn), dtype=np.uint8)
     with open(os.path.join(work, "time.txt")) as fh:
         out["file_time_txt"] = np.array(fh.read())
     with open(os.path.join(work, "param_basin.txt")) as fh:

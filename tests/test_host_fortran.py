@@ -1,0 +1,78 @@
+"""The Fortran-95 host (beom_amd/host): `module private_mod` exporting `run`, calling the
+HIP engine through iso_c_binding.
+
+CPU: it compiles and links (a) against a generated shared_mod + a 6-line main, and
+(b) — where /root/reference exists — against the reference's UNCHANGED main.f95 and
+shared_mod.f95: the drop-in.
+GPU: the built executable is run on the golden cases' input files and every output file
+of the reference's contract (grid.bin, h_0.bin, param_basin.txt, time.txt, eta_, u___,
+v___ and the diag fields) is compared byte for byte with the file the real reference
+wrote (tide case: real*4 values within 2e-6 relative — device cos())."""
+import os
+import shutil
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from beom_amd import inputs
+from beom_amd.host import build_host
+from helpers import Golden, golden_names
+
+REF = "/root/reference"
+HAVE_FLANG = os.path.exists(build_host.FLANG)
+
+
+@pytest.mark.skipif(not HAVE_FLANG, reason="flang not present")
+def test_host_compiles_with_generated_shared_mod(tmp_path):
+    p, _ = inputs.case_stommel(lm=24, mm=16, dt_s=0.2)
+    exe = build_host.build(p, str(tmp_path / "beom_gpu"))
+    assert os.path.exists(exe)
+    nm = subprocess.run(["nm", "-u", exe], capture_output=True, text=True).stdout
+    for sym in ("beom_create", "beom_upload_state", "beom_step", "beom_download_state", "beom_sync"):
+        assert sym in nm, sym          # the time loop goes through the C-ABI
+
+
+@pytest.mark.skipif(not (HAVE_FLANG and os.path.isdir(REF)), reason="needs flang and /root/reference")
+def test_drop_in_under_unchanged_reference_main_and_shared_mod(tmp_path):
+    """main.f95 and shared_mod.f95 are taken from the reference as they are."""
+    exe = build_host.build(None, str(tmp_path / "beom_gpu_ref"),
+                           shared_mod_path=os.path.join(REF, "shared_mod.f95"),
+                           main_path=os.path.join(REF, "main.f95"))
+    assert os.path.exists(exe)
+
+
+def _run_host(g, work):
+    exe = build_host.build(g.p, os.path.join(work, "beom_gpu"), variant=g.variant)
+    inputs.write_inputs(work, g.files)
+    r = subprocess.run([exe], cwd=work, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ERROR CODE" not in r.stderr, (r.stdout[-1500:], r.stderr[-1500:])
+    return r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not HAVE_FLANG, reason="flang not present")
+@pytest.mark.parametrize("name", golden_names())
+def test_fortran_host_reproduces_reference_output_files(name):
+    g = Golden(name)
+    work = tempfile.mkdtemp(prefix="beom_host_")
+    try:
+        out = _run_host(g, work)
+        assert "MI355X engine" in out
+        for key in [k for k in g.z.files if k.startswith("file_")]:
+            fn = key[5:].replace("_bin", ".bin").replace("_txt", ".txt")
+            path = os.path.join(work, fn)
+            assert os.path.exists(path), fn
+            if fn.endswith(".txt"):
+                assert open(path).read() == str(g.z[key]), fn
+                continue
+            mine = np.fromfile(path, dtype=np.uint8)
+            ref = g.z[key]
+            if g.uses_cos() and fn in ("eta_.bin", "u___.bin", "v___.bin"):
+                a = mine.view("<f4").astype(np.float64); b = ref.view("<f4").astype(np.float64)
+                assert a.shape == b.shape and np.max(np.abs(a - b)) <= 2e-6 * max(np.max(np.abs(b)), 1e-30), fn
+            else:
+                assert np.array_equal(mine, ref), fn
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
