@@ -74,7 +74,8 @@ __device__ __forceinline__ void body_update_h(const C &c, const DevView &d, doub
             rhsi = rs_3 * d.dt;               // (..)*dt*0 + rs_3*dt*(1-0)
         }
         hold = hold + rhsi;
-        double hnew = hold;
+        // unforced: hfor*0 + (1-0)*hold with hfor = fnud_n >= +0  ==  (+0) + hold (turns -0 into +0)
+        double hnew = 0.0 + hold;
         if (FORCED) {
             double hfor = FNUD_(ipnt, ilay, 1);
             if (d.has_tide) {
@@ -308,8 +309,10 @@ __device__ __forceinline__ void body_update_uv(const C &c, const DevView &d, int
         rhsi = rhsi - T3_(d.tb3d, ipnt, ID, ilay) * i_r0 * i__h;
         rhsi = rhsi - T3_(d.tu3d, ipnt, ID, ilay) * i_r0 * i__h;
     }
-    if (d.has_bodf) rhsi = rhsi + d.bodf[(ilay - 1) + d.nlay * (ID - 1)];
-    if (gene != 0.0) {
+    rhsi = rhsi + (d.has_bodf ? d.bodf[(ilay - 1) + d.nlay * (ID - 1)] : 0.0);   // + (+0) is not a no-op for -0
+    // gene = 0 (steps 1-3, g_fb = 0): the term is (finite)*0 = +-0 and only matters for the sign of
+    // an exactly-zero rhsi; fetch the history on those (rare) lanes only.
+    if (gene != 0.0 || rhsi == 0.0) {
         rhsi = rhsi + (d.del1 * dmd4 + d.del2 * LL(dm[2], ipnt, ilay) + d.gamm * LL(dm[1], ipnt, ilay)
                        + d.epsi * LL(dm[0], ipnt, ilay)) * gene;
     }
@@ -322,16 +325,21 @@ __device__ __forceinline__ void body_update_uv(const C &c, const DevView &d, int
         else      rhsi = rhsi + (vc0 * dv0 - vcb * dvb) * i_dl + (vla * rva - vl0 * rv0) * i_dl;
     }
     vold = vold + rhsi * mask * d.dt;
-    if (d.has_nudg) {
+    // Without nudging the reference still evaluates vfor*0 + vold*(1-0); that differs from vold only
+    // in the sign of an exact zero, so those (rare) lanes alone go through the full expression.
+    if (d.has_nudg || vold == 0.0) {
         const double i__hh = 1.0 / (hcen + 1.0 - mask);
         double vfor = FNUD_(ipnt, ilay, IV);
         if (d.has_stress) {
             const double ek = 0.5 * (T3_(d.tt3d, ipnt, IO, ilay) + T3_(d.tt3d, cb, IO, ilay))
                               * i_r1 * d.invf * i__hh * ramp;
             vfor = XDIR ? vfor + ek : vfor - ek;
+        } else {
+            vfor = XDIR ? vfor + 0.0 : vfor - 0.0;                      // the Ekman term is +0 then
         }
         if (d.has_tide) vfor = vfor + ramp * TIDE_(1, ipnt, IV) * cos(TIDE_(2, ipnt, IV) - d.w_ti * ctim);
-        const double ng = NUDG_(ipnt, IV);
+        else vfor = vfor + 0.0;                                         // ramp*0*cos(0)
+        const double ng = d.has_nudg ? NUDG_(ipnt, IV) : 0.0;
         vold = vfor * ng + vold * (1.0 - ng);
     }
     LL(vel, ipnt, ilay) = vold;

@@ -41,7 +41,7 @@ def build(p: Optional[Params], out_exe: str, shared_mod_path: Optional[str] = No
             assert txt.count("prm%variant = 0") == 1
             host_src = os.path.join(work, "beom_host_mod.f95")
             with open(host_src, "w") as f:
-                f.write(txt.replace("prm%variant = 0", "prm%variant = %d" % variant))
+                f.write(txt.replace("prm%variant = 0", "prm%variant = " + str(int(variant))))
         if shared_mod_path is None:
             shared_mod_path = os.path.join(work, "shared_mod.f95")
             with open(shared_mod_path, "w") as f:

@@ -83,6 +83,8 @@ void oracle_update_h(const beom_params *P, oracle_state *S, double gene, double 
             if (S->tide)
                 hfor = hfor + ramp * TIDE(1, ipnt, IX_N) * vecl
                             * cos(TIDE(2, ipnt, IX_N) - P->w_ti * ctim); /* :1632-1634 */
+            else
+                hfor = hfor + 0.0;          /* tide == 0: the term is +0, which turns a -0 into +0 */
             const double ng = NUDG(ipnt, IX_N);
             if (P->variant == 0) {
                 L2(S->hlay, ipnt, ilay) = hfor * ng + (1.0 - ng) * hold;   /* :1637-1638 */
@@ -226,6 +228,8 @@ void oracle_update_u(const beom_params *P, oracle_state *S, int ilay,
                       * i_r1 * P->invf * i__h * ramp;                        /* :1450-1452 */
         if (S->tide)
             ufor = ufor + ramp * TIDE(1, ipnt, IX_U) * cos(TIDE(2, ipnt, IX_U) - P->w_ti * ctim); /* :1453 */
+        else
+            ufor = ufor + 0.0;
         double rhsi = dmd4 * (1.0 - gene)
                     + 0.25 * S->pvor[ipnt] * (L2(S->h_v, ipnt, ilay) + L2(S->h_v, c5, ilay))
                     + 0.25 * S->pvor[c3] * (L2(S->h_v, c3, ilay) + L2(S->h_v, c4, ilay))
@@ -272,6 +276,8 @@ void oracle_update_v(const beom_params *P, oracle_state *S, int ilay,
                       * i_r1 * P->invf * i__h * ramp;                        /* :1535-1537 */
         if (S->tide)
             vfor = vfor + ramp * TIDE(1, ipnt, IX_V) * cos(TIDE(2, ipnt, IX_V) - P->w_ti * ctim); /* :1538 */
+        else
+            vfor = vfor + 0.0;
         double rhsi = dmd4 * (1.0 - gene)
                     - 0.25 * S->pvor[ipnt] * (L2(S->h_u, ipnt, ilay) + L2(S->h_u, c7, ilay))
                     - 0.25 * S->pvor[c1] * (L2(S->h_u, c1, ilay) + L2(S->h_u, c8, ilay))

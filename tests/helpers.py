@@ -48,6 +48,12 @@ def same(a, b):
     return a.shape == b.shape and bool(np.all((a == b) | (np.isnan(a) & np.isnan(b))))
 
 
+def same_bits(a, b):
+    """Bit-identical, the sign of zero included."""
+    a = np.ascontiguousarray(a, dtype=np.float64); b = np.ascontiguousarray(b, dtype=np.float64)
+    return a.shape == b.shape and bool(np.array_equal(a.view(np.uint64), b.view(np.uint64)))
+
+
 def maxrel(a, b):
     a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
     scale = max(float(np.max(np.abs(b))), 1e-300)

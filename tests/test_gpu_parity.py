@@ -8,7 +8,7 @@ import pytest
 
 import oracle_lib
 from beom_amd import capi
-from helpers import GOLDEN_STEPS, SCRATCH, STATE, Golden, golden_names, maxrel, same
+from helpers import GOLDEN_STEPS, SCRATCH, STATE, Golden, golden_names, maxrel, same, same_bits
 
 pytestmark = pytest.mark.gpu
 NAMES = golden_names()
@@ -42,6 +42,9 @@ def test_step_matches_reference_golden(name, dense_hint):
         st = e.download()
         for k in STATE:
             _check(st[k], g.step(tgt, k), exact, (name, tgt, k))
+        if exact:                                  # prognostic fields: even the sign of zero
+            for k in ("hlay", "u", "v", "h_u", "h_v"):
+                assert same_bits(st[k], g.step(tgt, k)), (name, tgt, k, "sign of zero")
         sc = e.download_scratch()
         for k in SCRATCH:                      # reference scratch = last layer processed
             _check(sc[k][g.p.nlay - 1], g.step(tgt, k), exact, (name, tgt, k))
