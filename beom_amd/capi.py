@@ -102,6 +102,7 @@ def load(path: Optional[str] = None) -> C.CDLL:
     lib.beom_step.argtypes = [H, ci, ci, cd, cd, cd, cd, ci, cp, ci]
     lib.beom_sync.argtypes = [H, cp, ci]
     lib.beom_set_stream.argtypes = [H, C.c_void_p]
+    lib.beom_set_option.argtypes = [H, cp, ci]
     lib.beom_profile_start.argtypes = [H]
     lib.beom_profile_stop.argtypes = [H, dpp, C.POINTER(ci), cp, ci]
     lib.beom_update_h.argtypes = [H, cd, cd, cd]
@@ -120,7 +121,7 @@ def load(path: Optional[str] = None) -> C.CDLL:
                  "beom_update_h", "beom_update_mont_rvor_pvor_dive_kine", "beom_update_viscosity",
                  "beom_update_u", "beom_update_v", "beom_rebuild_fluxes", "beom_distribute_stress",
                  "beom_device_field", "beom_is_dense", "beom_profile_steps", "beom_set_stream",
-                 "beom_profile_start", "beom_profile_stop"):
+                 "beom_profile_start", "beom_profile_stop", "beom_set_option"):
         getattr(lib, name).restype = ci
     if lib.beom_abi_version() != BEOM_ABI_VERSION:
         raise RuntimeError("ABI mismatch")
@@ -133,7 +134,7 @@ EXPORTS = ("beom_abi_version", "beom_device_count", "beom_create", "beom_destroy
            "beom_sync", "beom_update_h", "beom_update_mont_rvor_pvor_dive_kine",
            "beom_update_viscosity", "beom_update_u", "beom_update_v", "beom_rebuild_fluxes",
            "beom_distribute_stress", "beom_device_field", "beom_is_dense", "beom_profile_steps",
-           "beom_set_stream", "beom_profile_start", "beom_profile_stop")
+           "beom_set_stream", "beom_profile_start", "beom_profile_stop", "beom_set_option")
 
 STATE_NAMES = ("hlay", "u", "v", "h_u", "h_v", "rs_h", "dmdx", "dmdy", "v_cc", "v_ll",
                "tt3d", "tb3d", "tu3d")
@@ -213,6 +214,9 @@ class Engine:
     def set_stream(self, hip_stream: Optional[int]):
         """hip_stream: integer handle (e.g. torch.cuda.current_stream().cuda_stream) or None."""
         self._check(self.lib.beom_set_stream(self.h, C.c_void_p(hip_stream) if hip_stream else None))
+
+    def set_option(self, name: str, value: int):
+        self._check(self.lib.beom_set_option(self.h, name.encode(), int(value)))
 
     def profile_start(self):
         self._check(self.lib.beom_profile_start(self.h))

@@ -30,6 +30,9 @@ struct DevView {
     double *v_cc, *v_ll, *tt3d, *tb3d, *tu3d;
     // per-layer diagnostics (0:ndeg, nlay)
     double *mont, *rvor, *pvor, *dive, *d2hx, *d2hy;
+    // fused Montgomery+Leith sweep: products v_cc*dive and v_ll*rvor (0:ndeg, nlay)
+    double *pcd, *qlr;
+    int keep_diag;                // fused sweep also stores rvor, dive, v_cc, v_ll
     // stress work arrays
     double *layt, *layb, *layu, *taub, *taum;
     // constants by value
@@ -121,6 +124,12 @@ struct CellDenseT {
         ipnt = i + (j - 1) * L;
         jg = j + d.joff; Mg = d.Mg; ywrap = d.yper && !d.slab;
         return j <= M && i <= L;
+    }
+    // context of an arbitrary LOCAL cell (a, b) of the same frame (used for halo cells)
+    __device__ __forceinline__ void set_cell(const DevView &d, int a, int b) {
+        L = d.L; M = d.M; xper = d.xper; yper = d.yper;
+        i = a; j = b; ipnt = a + (b - 1) * L;
+        jg = b + d.joff; Mg = d.Mg; ywrap = d.yper && !d.slab;
     }
     // wave-uniform: do all 64 cells of this wave satisfy 2 <= i <= L-2, 2 <= j <= M-2 ?
     __device__ __forceinline__ bool wave_is_interior() const {

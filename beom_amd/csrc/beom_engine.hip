@@ -48,6 +48,7 @@ struct beom_engine {
     // geometry of the launches
     dim3 grid_cells0, grid_cells_layers_flat;
     bool wind = false, bot = false, top = false;
+    bool fuse = true;                  // dense frames: Montgomery+Leith in one sweep (k_mont_visc)
     char last_err[512] = {0};
 };
 
@@ -199,6 +200,8 @@ int beom_create(const beom_params *prm, int device, const int32_t *neig, const i
     d.has_bodf = any_nonzero(bodf, 2 * nl);
     d.has_nudg = any_nonzero(nudg, 3 * n1);
     d.has_hto = any_nonzero(h_to, n1);
+    d.keep_diag = 0;
+    E->fuse = getenv("BEOM_NO_FUSE") == nullptr;
     E->wind = false;
     if (taus) for (size_t i = 0; i < 2 * n1; ++i) if (std::fabs(taus[i]) > 1.e-7) { E->wind = true; break; }   // :1945
     E->bot = prm->bdrg > 1.e-7;                                                                                  // :1969
@@ -212,6 +215,7 @@ int beom_create(const beom_params *prm, int device, const int32_t *neig, const i
     AL(dmy[0], nl * n1) AL(dmy[1], nl * n1) AL(dmy[2], nl * n1)
     AL(v_cc, nl * n1) AL(v_ll, nl * n1)
     AL(tt3d, 2 * nl * n1) AL(tb3d, 2 * nl * n1) AL(tu3d, 2 * nl * n1)
+    AL(pcd, nl * n1) AL(qlr, nl * n1)
     AL(mont, nl * n1) AL(rvor, nl * n1) AL(pvor, nl * n1) AL(dive, nl * n1) AL(d2hx, nl * n1) AL(d2hy, nl * n1)
     if (E->wind) AL(layt, nl * n1)
     if (E->bot) { AL(layb, nl * n1) AL(taub, 2 * n1) }
@@ -402,11 +406,27 @@ static void launch_visc(beom_engine *E, int ilay) {
     LAUNCH_CTX(k_update_visc<CellGather>, k_update_visc<CellDense>, nz, E->d, ilay);
 }
 template <bool XDIR>
-static void launch_uv(beom_engine *E, int ilay, double gene, double ramp, double ctim) {
+static void launch_uv(beom_engine *E, int ilay, double gene, double ramp, double ctim, bool prod = false) {
     const int nz = ilay ? 1 : E->d.nlay;
     const int copy_hist = ilay ? 1 : 0;       // a single-layer call cannot rotate shared pointers
-    LAUNCH_CTX((k_update_uv<CellGather, XDIR>), (k_update_uv<CellDense, XDIR>), nz, E->d, ilay, gene, ramp, ctim, copy_hist);
+    if (prod) hipLaunchKernelGGL((k_update_uv<CellDense, XDIR, true>), CellDense::grid(E->d, nz), dim3(BEOM_BLOCK), 0, E->stream, E->d, ilay, gene, ramp, ctim, copy_hist);
+    else LAUNCH_CTX((k_update_uv<CellGather, XDIR>), (k_update_uv<CellDense, XDIR>), nz, E->d, ilay, gene, ramp, ctim, copy_hist);
     if (!copy_hist) { if (XDIR) rot3(E->d.dmx); else rot3(E->d.dmy); }
+}
+// fused Montgomery + Leith sweep (dense frames); false if no instantiation for this nlay
+static bool launch_mont_visc(beom_engine *E) {
+    const dim3 g = mont_visc_grid(E->d), b(BEOM_BLOCK);
+    switch (E->d.nlay) {
+#define CASE_NL(n) case n: hipLaunchKernelGGL((k_mont_visc<n>), g, b, 0, E->stream, E->d); return true;
+        CASE_NL(1) CASE_NL(2) CASE_NL(3) CASE_NL(4) CASE_NL(5) CASE_NL(6) CASE_NL(8)
+#undef CASE_NL
+        default: return false;
+    }
+}
+static bool can_fuse(const beom_engine *E, int n_3d) {
+    // every step must refresh the viscosity (else v_cc/v_ll have to persist): dvis > 1e-3 and n_3d = 1 (:2268)
+    const int nl = E->d.nlay;
+    return E->dense && E->fuse && E->P.dvis > 1.e-3 && n_3d == 1 && (nl <= 6 || nl == 8);
 }
 static void launch_stress(beom_engine *E) {
     if (!(E->wind || E->bot || E->top)) return;
@@ -434,7 +454,7 @@ int beom_distribute_stress(beom_handle E) { NEED(E); launch_stress(E); return 0;
 }  // extern "C"
 
 // Per-step scalars of integrate_time (private_mod.f95:1858-1901).
-struct StepScalars { double ctim, ramp, gene; bool first3, upst, stress; };
+struct StepScalars { double ctim, ramp, gene; bool first3, upst, stress, fused; };
 static StepScalars step_scalars(const beom_engine *E, int tstp, double tres, double dtd8, double dt_r,
                                 double rsta, int n_3d) {
     StepScalars s;
@@ -452,6 +472,7 @@ static StepScalars step_scalars(const beom_engine *E, int tstp, double tres, dou
         s.stress = s.upst;                                         // :1894-1896
     }
     s.gene = s.first3 ? 0.0 : E->P.g_fb;                           // :1859,1877
+    s.fused = can_fuse(E, n_3d);
     return s;
 }
 
@@ -470,24 +491,25 @@ static void one_step(beom_engine *E, int tstp, const StepScalars &s) {
     if (T) T->begin(0);
     launch_h(E, s.gene, s.ramp, s.ctim);                           // :2181,2259
     if (T) { T->end(); T->begin(1); }
-    launch_mont(E, 0);                                             // :2187,2266
+    const bool prod = s.fused && launch_mont_visc(E);              // :2187-2188, 2266-2269 in one sweep
+    if (!prod) launch_mont(E, 0);
     if (T) T->end();
-    if (s.first3 || (E->P.dvis > 1.e-3 && s.upst)) {               // :2188,2268
+    if (!prod && (s.first3 || (E->P.dvis > 1.e-3 && s.upst))) {     // :2188,2268
         if (T) T->begin(2);
         launch_visc(E, 0);
         if (T) T->end();
     }
     if (tstp % 2 == 0) {                                           // :2193-2199,2276-2282
         if (T) T->begin(3);
-        launch_uv<true>(E, 0, s.gene, s.ramp, s.ctim);
+        launch_uv<true>(E, 0, s.gene, s.ramp, s.ctim, prod);
         if (T) { T->end(); T->begin(4); }
-        launch_uv<false>(E, 0, s.gene, s.ramp, s.ctim);
+        launch_uv<false>(E, 0, s.gene, s.ramp, s.ctim, prod);
         if (T) T->end();
     } else {
         if (T) T->begin(4);
-        launch_uv<false>(E, 0, s.gene, s.ramp, s.ctim);
+        launch_uv<false>(E, 0, s.gene, s.ramp, s.ctim, prod);
         if (T) { T->end(); T->begin(3); }
-        launch_uv<true>(E, 0, s.gene, s.ramp, s.ctim);
+        launch_uv<true>(E, 0, s.gene, s.ramp, s.ctim, prod);
         if (T) T->end();
     }
 }
@@ -540,6 +562,14 @@ int beom_profile_steps(beom_handle E, int tstp_first, int nsteps, double tres, d
     rc = beom_step(E, tstp_first, nsteps, tres, dtd8, dt_r, rsta, n_3d, errm, errm_len);
     if (rc) return rc;
     return beom_profile_stop(E, ms, launches, errm, errm_len);
+}
+
+int beom_set_option(beom_handle E, const char *name, int value) {
+    if (!E || !name) return -1;
+    if (!strcmp(name, "fuse")) E->fuse = value != 0;
+    else if (!strcmp(name, "keep_diag")) E->d.keep_diag = value != 0;
+    else return -3;
+    return 0;
 }
 
 int beom_set_stream(beom_handle E, void *hip_stream) {

@@ -242,6 +242,189 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_update_mont_all(DevView d) {
     else body_update_mont_all<NL>(c, d);
 }
 
+// ---- fused sweep: update_mont_rvor_pvor_dive_kine (:2318-2439) + update_viscosity
+//      (:2441-2502) for dense frames.  rvor and dive of a 64 x 8 tile plus a one-cell ring
+//      are staged in LDS (double-buffered over layers, one barrier per layer); the Leith
+//      stencil reads them from LDS, and the sweep hands update_u/update_v the products
+//          pcd = v_cc*dive   and   qlr = v_ll*rvor
+//      which is all they use of the four arrays (:1476-1479, :1561-1564); each product is
+//      rounded before the differences are taken, exactly as in the reference.  Saves the
+//      Leith launch, its 4 words, and 2 words in each momentum sweep.  With keep_diag the
+//      four arrays are stored as well (parity tests; needed when viscosity is not refreshed
+//      every step — then the unfused path runs instead).
+#define MV_TX 64
+#define MV_TY 8
+#define MV_LDX (MV_TX + 2 + 1)          // +1 pad column
+#define MV_LDY (MV_TY + 2)
+
+template <bool INT>
+__device__ __forceinline__ void rv_dv_at(const DevView &d, const CellDenseT<INT> &c, int ilay,
+                                         double &rv, double &dv, double &u_le, double &u_ri,
+                                         double &v_bo, double &v_to) {
+    const int ipnt = c.ipnt;
+    const int c1 = c.template nb<1>(), c3 = c.template nb<3>(), c5 = c.template nb<5>(), c7 = c.template nb<7>();
+    u_le = LL(d.u, ipnt, ilay); u_ri = LL(d.u, c1, ilay);
+    v_bo = LL(d.v, ipnt, ilay); v_to = LL(d.v, c3, ilay);
+    rv = (v_bo - LL(d.v, c5, ilay) - u_le + LL(d.u, c7, ilay)) * d.i_dl * c.mkpe();
+    dv = (u_ri - u_le + v_to - v_bo) * d.i_dl;
+}
+
+// rvor/dive of the (possibly wrapped / out-of-frame) local target cell (a, b)
+template <bool INT>
+__device__ __forceinline__ void rv_dv_halo(const DevView &d, int a, int b, int ilay, double &rv, double &dv) {
+    rv = 0.0; dv = 0.0;                      // sentinel: rvor(0) = dive(0) = 0 (:273,275)
+    if (!INT) {
+        if (d.xper) { if (a == 0) a = d.L - 1; else if (a == d.L) a = 1; }
+        if (d.yper && !d.slab) { if (b == 0) b = d.M - 1; else if (b == d.M) b = 1; }
+        if (a < 1 || a > d.L || b < 1 || b > d.M) return;
+    }
+    CellDenseT<INT> h;
+    h.set_cell(d, a, b);
+    double t0, t1, t2, t3;
+    rv_dv_at<INT>(d, h, ilay, rv, dv, t0, t1, t2, t3);
+}
+
+template <int NL, bool INT>
+__device__ __forceinline__ void body_mont_visc(const DevView &d, int x0, int y0,
+                                               double (*s_rv)[MV_LDY][MV_LDX], double (*s_dv)[MV_LDY][MV_LDX]) {
+    const int tid = threadIdx.x;
+    const int lx = tid & 63, wy = tid >> 6;              // column in tile, wave = row pair
+    const int i = x0 + lx;
+    const double i_gr = d.i_gr, i_ns = d.i_ns, hs_8 = d.hsal;
+    // own cells: rows y0+wy and y0+wy+4
+    CellDenseT<INT> c[2];
+    bool ok[2];
+    double h[2][NL], hcol[2], fcor[2], h_th[2], h_to[2];
+    int n1[2], n3[2], n5[2], n6[2], n7[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int j = y0 + wy + 4 * q;
+        ok[q] = (i <= d.L) && (j <= d.M);
+        c[q].set_cell(d, ok[q] ? i : 1, ok[q] ? j : 1);
+        n1[q] = c[q].template nb<1>(); n3[q] = c[q].template nb<3>(); n5[q] = c[q].template nb<5>();
+        n6[q] = c[q].template nb<6>(); n7[q] = c[q].template nb<7>();
+        fcor[q] = d.fcor[c[q].ipnt]; h_th[q] = d.h_th[c[q].ipnt];
+        h_to[q] = d.has_hto ? d.h_to[c[q].ipnt] : 0.0;
+        hcol[q] = 0.0;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) h[q][l] = LL(d.hlay, c[q].ipnt, l + 1);
+#pragma unroll
+        for (int l = 0; l < NL; ++l) hcol[q] = hcol[q] + h[q][l];
+    }
+    // halo cell of this thread (threads 0..147): ring of the 66 x 10 region
+    int ha = 0, hb = 0, hr = -1, hc = -1;
+    if (tid < MV_TX + 2) { hr = 0; hc = tid; }
+    else if (tid < 2 * (MV_TX + 2)) { hr = MV_TY + 1; hc = tid - (MV_TX + 2); }
+    else if (tid < 2 * (MV_TX + 2) + MV_TY) { hr = 1 + tid - 2 * (MV_TX + 2); hc = 0; }
+    else if (tid < 2 * (MV_TX + 2) + 2 * MV_TY) { hr = 1 + tid - 2 * (MV_TX + 2) - MV_TY; hc = MV_TX + 1; }
+    if (hr >= 0) { ha = x0 - 1 + hc; hb = y0 - 1 + hr; }
+
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        const int ilay = l + 1, buf = l & 1;
+        double rv[2], dv[2], u_le[2], u_ri[2], v_bo[2], v_to[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            rv[q] = 0.0; dv[q] = 0.0; u_le[q] = u_ri[q] = v_bo[q] = v_to[q] = 0.0;
+            if (ok[q]) rv_dv_at<INT>(d, c[q], ilay, rv[q], dv[q], u_le[q], u_ri[q], v_bo[q], v_to[q]);
+            s_rv[buf][1 + wy + 4 * q][1 + lx] = rv[q];
+            s_dv[buf][1 + wy + 4 * q][1 + lx] = dv[q];
+        }
+        if (hr >= 0) {
+            double a, b;
+            rv_dv_halo<INT>(d, ha, hb, ilay, a, b);
+            s_rv[buf][hr][hc] = a;
+            s_dv[buf][hr][hc] = b;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (!ok[q]) continue;
+            const CellDenseT<INT> &cc = c[q];
+            const int ipnt = cc.ipnt;
+            const int r = 1 + wy + 4 * q, cx = 1 + lx;
+            const double mkn = cc.mk_n(), mkpi = cc.mkpi();
+            const double mk1 = cc.template mk_n_nb<1>(n1[q]), mk3 = cc.template mk_n_nb<3>(n3[q]),
+                         mk5 = cc.template mk_n_nb<5>(n5[q]), mk6 = cc.template mk_n_nb<6>(n6[q]),
+                         mk7 = cc.template mk_n_nb<7>(n7[q]);
+            const double h0 = h[q][l];
+            double mpot = -0.0;
+            if (d.ocrp != 0.0) {
+                mpot = h0 + d.hmin * (1.0 - mkn);
+                mpot = powi_dev(d.hsal / mpot, d.nsal - 1);
+                mpot = mpot * (-d.ocrp * i_ns * d.hsal * mkn);
+            }
+            mpot = mpot - h_to[q];
+            const double i_rn = d.i_rn[l];
+#pragma unroll
+            for (int m = 0; m < l; ++m) mpot = mpot - (d.rhon[l] - d.rhon[m]) * i_rn * h[q][m];
+            if (d.rgld < 0.5) mpot = hcol[q] - h_th[q] + mpot;
+            LL(d.mont, ipnt, ilay) = mpot + 0.25 * d.uadv * i_gr
+                                          * (u_ri[q] * u_ri[q] + u_le[q] * u_le[q] + v_to[q] * v_to[q] + v_bo[q] * v_bo[q]);
+            const double hE = LL(d.hlay, n1[q], ilay), hW = LL(d.hlay, n5[q], ilay),
+                         hN = LL(d.hlay, n3[q], ilay), hS = LL(d.hlay, n7[q], ilay);
+            double d2x = (hE + hW - h0 * 2.0) * mk1 * mk5 * mkn;
+            double d2y = (hN + hS - h0 * 2.0) * mk3 * mk7 * mkn;
+            if (d.ocrp > 0.5) {
+                if (hE < 2.0 * hs_8 || hW < 2.0 * hs_8 || h0 < 2.0 * hs_8) d2x = 0.0;
+                if (hN < 2.0 * hs_8 || hS < 2.0 * hs_8 || h0 < 2.0 * hs_8) d2y = 0.0;
+            }
+            LL(d.d2hx, ipnt, ilay) = d2x;
+            LL(d.d2hy, ipnt, ilay) = d2y;
+            const double have = h0 + hW + LL(d.hlay, n6[q], ilay) + hS;
+            LL(d.pvor, ipnt, ilay) = (fcor[q] + rv[q] * d.uadv) * mkpi * (mkn + mk5 + mk6 + mk7) / have;
+            // Leith viscosity from the staged ring (same names as :2458-2470)
+            const double r_bl = rv[q], r_br = s_rv[buf][r][cx + 1], r_tr = s_rv[buf][r + 1][cx + 1],
+                         r_tl = s_rv[buf][r + 1][cx], rbll = s_rv[buf][r][cx - 1], rbbl = s_rv[buf][r - 1][cx];
+            const double d_cc = dv[q], d_ri = s_dv[buf][r][cx + 1], d_to = s_dv[buf][r + 1][cx],
+                         d_le = s_dv[buf][r][cx - 1], d_bl = s_dv[buf][r - 1][cx - 1], d_bo = s_dv[buf][r - 1][cx];
+            double a = (r_br - r_bl) * (r_br - r_bl) + (r_bl - rbll) * (r_bl - rbll)
+                     + (r_tl - r_bl) * (r_tl - r_bl) + (r_bl - rbbl) * (r_bl - rbbl)
+                     + (d_cc - d_le) * (d_cc - d_le) + (d_bo - d_bl) * (d_bo - d_bl)
+                     + (d_cc - d_bo) * (d_cc - d_bo) + (d_le - d_bl) * (d_le - d_bl);
+            const double vll = sqrt(a) * d.dvis * d.dl * d.dl + d.bvis;
+            double b = (r_br - r_bl) * (r_br - r_bl) + (r_tr - r_tl) * (r_tr - r_tl)
+                     + (r_tl - r_bl) * (r_tl - r_bl) + (r_tr - r_br) * (r_tr - r_br)
+                     + (d_ri - d_cc) * (d_ri - d_cc) + (d_cc - d_le) * (d_cc - d_le)
+                     + (d_to - d_cc) * (d_to - d_cc) + (d_cc - d_bo) * (d_cc - d_bo);
+            const double vcc = sqrt(b) * d.dvis * d.dl * d.dl + d.bvis;
+            LL(d.pcd, ipnt, ilay) = vcc * d_cc;
+            LL(d.qlr, ipnt, ilay) = vll * r_bl;
+            if (d.keep_diag) {
+                LL(d.rvor, ipnt, ilay) = r_bl; LL(d.dive, ipnt, ilay) = d_cc;
+                LL(d.v_cc, ipnt, ilay) = vcc;  LL(d.v_ll, ipnt, ilay) = vll;
+            }
+        }
+    }
+}
+
+template <int NL>
+__global__ __launch_bounds__(BEOM_BLOCK) void k_mont_visc(DevView d) {
+    __shared__ double s_rv[2][MV_LDY][MV_LDX];
+    __shared__ double s_dv[2][MV_LDY][MV_LDX];
+    // XCD-aware tile order: XCD x sweeps its own band of tile rows
+    const int gx = (d.L + MV_TX - 1) / MV_TX;
+    const int gy = (d.M + MV_TY - 1) / MV_TY;
+    const int rpx = (gy + 7) / 8;
+    const int b = blockIdx.x;
+    const int xcd = b & 7, k = b >> 3;
+    const int rib = k / gx, ch = k - rib * gx;
+    const int ty = xcd * rpx + rib;
+    if (ty >= gy) return;                                   // whole block: no barrier is skipped by part of it
+    const int x0 = ch * MV_TX + 1, y0 = ty * MV_TY + 1;
+    // block-uniform: tile and its ring lie in 2..L-2 x 2..M-2 (global rows too) -> no wraps, masks = 1
+    const bool interior = x0 - 1 >= 2 && x0 + MV_TX <= d.L - 2 && y0 - 1 >= 2 && y0 + MV_TY <= d.M - 2
+                          && y0 - 1 + d.joff >= 2 && y0 + MV_TY + d.joff <= d.Mg - 2;
+    if (interior) body_mont_visc<NL, true>(d, x0, y0, s_rv, s_dv);
+    else body_mont_visc<NL, false>(d, x0, y0, s_rv, s_dv);
+}
+static inline dim3 mont_visc_grid(const DevView &d) {
+    const int gx = (d.L + MV_TX - 1) / MV_TX;
+    const int gy = (d.M + MV_TY - 1) / MV_TY;
+    const int rpx = (gy + 7) / 8;
+    return dim3((unsigned)(8 * rpx * gx), 1, 1);
+}
+
 // ---- update_viscosity (Leith part), private_mod.f95:2441-2502 -----------------------
 template <class C>
 __device__ __forceinline__ void body_update_visc(const C &c, const DevView &d, int ilay_only) {
@@ -274,7 +457,7 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_update_visc(DevView d, int ilay_
 
 // ---- update_u (XDIR=true, private_mod.f95:1422-1503) and update_v (XDIR=false,
 //      :1505-1591).  The two routines are mirror images: W<->S, N<->E, NW<->SE. -------
-template <bool XDIR, class C>
+template <bool XDIR, bool PROD, class C>
 __device__ __forceinline__ void body_update_uv(const C &c, const DevView &d, int ilay_only, double gene,
                                                           double ramp, double ctim, int copy_hist) {
     const int ipnt = c.ipnt;
@@ -316,7 +499,12 @@ __device__ __forceinline__ void body_update_uv(const C &c, const DevView &d, int
         rhsi = rhsi + (d.del1 * dmd4 + d.del2 * LL(dm[2], ipnt, ilay) + d.gamm * LL(dm[1], ipnt, ilay)
                        + d.epsi * LL(dm[0], ipnt, ilay)) * gene;
     }
-    {
+    if (PROD) {       // products staged by k_mont_visc: pcd = v_cc*dive, qlr = v_ll*rvor
+        const double p0 = LL(d.pcd, ipnt, ilay), pb = LL(d.pcd, cb, ilay);
+        const double q0 = LL(d.qlr, ipnt, ilay), qa = LL(d.qlr, ca, ilay);
+        if (XDIR) rhsi = rhsi + (p0 - pb) * i_dl - (qa - q0) * i_dl;
+        else      rhsi = rhsi + (p0 - pb) * i_dl + (qa - q0) * i_dl;
+    } else {
         const double vc0 = LL(d.v_cc, ipnt, ilay), vcb = LL(d.v_cc, cb, ilay);
         const double vl0 = LL(d.v_ll, ipnt, ilay), vla = LL(d.v_ll, ca, ilay);
         const double dv0 = LL(d.dive, ipnt, ilay), dvb = LL(d.dive, cb, ilay);
@@ -355,13 +543,13 @@ __device__ __forceinline__ void body_update_uv(const C &c, const DevView &d, int
         LL(dm[0], ipnt, ilay) = dmd4;          // host rotates (dm0,dm1,dm2) <- (dm1,dm2,dm0)
     }
 }
-template <class CTX, bool XDIR>
+template <class CTX, bool XDIR, bool PROD = false>
 __global__ __launch_bounds__(BEOM_BLOCK) void k_update_uv(DevView d, int ilay_only, double gene,
                                                           double ramp, double ctim, int copy_hist) {
     CTX c;
     if (!c.init(d)) return;
-    if (c.wave_is_interior()) body_update_uv<XDIR>(c.as_interior(), d, ilay_only, gene, ramp, ctim, copy_hist);
-    else body_update_uv<XDIR>(c, d, ilay_only, gene, ramp, ctim, copy_hist);
+    if (c.wave_is_interior()) body_update_uv<XDIR, PROD>(c.as_interior(), d, ilay_only, gene, ramp, ctim, copy_hist);
+    else body_update_uv<XDIR, PROD>(c, d, ilay_only, gene, ramp, ctim, copy_hist);
 }
 
 // ---- distribute_stress, private_mod.f95:1921-2149 -----------------------------------

@@ -129,6 +129,13 @@ int beom_step(beom_handle h, int tstp_first, int nsteps,
 
 int beom_sync(beom_handle h, char *errm, int errm_len);
 
+/* Options: "fuse" (default 1; 0 = always five separate sweeps) — on dense frames with the
+ * Leith viscosity refreshed every step (dvis > 1e-3, n_3d = 1) update_mont... and
+ * update_viscosity run as ONE sweep that hands update_u/v the products v_cc*dive and
+ * v_ll*rvor; v_cc, v_ll, rvor, dive are then kept up to date only with "keep_diag" = 1
+ * (default 0).  Returns -3 for an unknown name. */
+int beom_set_option(beom_handle h, const char *name, int value);
+
 /* Run all launches of this handle on the caller's HIP stream (e.g. the stream a
  * ghost-row exchange is enqueued on); NULL restores the handle's own stream. */
 int beom_set_stream(beom_handle h, void *hip_stream);
