@@ -101,7 +101,7 @@ def load(path: Optional[str] = None) -> C.CDLL:
     lib.beom_download_scratch.argtypes = [H] + [dpp] * 6 + [cp, ci]
     lib.beom_step.argtypes = [H, ci, ci, cd, cd, cd, cd, ci, cp, ci]
     lib.beom_sync.argtypes = [H, cp, ci]
-    lib.beom_set_stream.argtypes = [H, C.c_void_p]
+    lib.beom_set_stream.argtypes = [H, C.c_void_p, ci]
     lib.beom_set_option.argtypes = [H, cp, ci]
     lib.beom_profile_start.argtypes = [H]
     lib.beom_profile_stop.argtypes = [H, dpp, C.POINTER(ci), cp, ci]
@@ -212,8 +212,12 @@ class Engine:
         self._check(self.lib.beom_sync(self.h, self._err, ERRLEN))
 
     def set_stream(self, hip_stream: Optional[int]):
-        """hip_stream: integer handle (e.g. torch.cuda.current_stream().cuda_stream) or None."""
-        self._check(self.lib.beom_set_stream(self.h, C.c_void_p(hip_stream) if hip_stream else None))
+        """hip_stream: integer handle (torch.cuda.current_stream().cuda_stream; 0 = the default
+        stream) — or None to go back to the handle's own stream."""
+        if hip_stream is None:
+            self._check(self.lib.beom_set_stream(self.h, None, 1))
+        else:
+            self._check(self.lib.beom_set_stream(self.h, C.c_void_p(hip_stream), 0))
 
     def set_option(self, name: str, value: int):
         self._check(self.lib.beom_set_option(self.h, name.encode(), int(value)))

@@ -572,9 +572,10 @@ int beom_set_option(beom_handle E, const char *name, int value) {
     return 0;
 }
 
-int beom_set_stream(beom_handle E, void *hip_stream) {
+int beom_set_stream(beom_handle E, void *hip_stream, int use_own) {
     if (!E) return -1;
-    E->stream = hip_stream ? (hipStream_t)hip_stream : E->own_stream;
+    // hip_stream == NULL is a valid stream (the legacy default stream torch uses by default)
+    E->stream = use_own ? E->own_stream : (hipStream_t)hip_stream;
     return 0;
 }
 

@@ -327,8 +327,16 @@ __device__ __forceinline__ void body_mont_visc(const DevView &d, int x0, int y0,
         for (int q = 0; q < 2; ++q) {
             rv[q] = 0.0; dv[q] = 0.0; u_le[q] = u_ri[q] = v_bo[q] = v_to[q] = 0.0;
             if (ok[q]) rv_dv_at<INT>(d, c[q], ilay, rv[q], dv[q], u_le[q], u_ri[q], v_bo[q], v_to[q]);
-            s_rv[buf][1 + wy + 4 * q][1 + lx] = rv[q];
-            s_dv[buf][1 + wy + 4 * q][1 + lx] = dv[q];
+            // The staged entry at a geometric position is what a NEIGHBOUR lookup of that target
+            // returns.  Under periodic wraps the orphan column i = L / row j = M are wrap targets
+            // (private_mod.f95:619-620,647-648): they must hold the wrapped cell's values.
+            double srv = rv[q], sdv = dv[q];
+            if (!INT) {
+                const int jq = y0 + wy + 4 * q;
+                if ((d.xper && i == d.L) || (d.yper && !d.slab && jq == d.M)) rv_dv_halo<INT>(d, i, jq, ilay, srv, sdv);
+            }
+            s_rv[buf][1 + wy + 4 * q][1 + lx] = srv;
+            s_dv[buf][1 + wy + 4 * q][1 + lx] = sdv;
         }
         if (hr >= 0) {
             double a, b;

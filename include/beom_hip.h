@@ -137,8 +137,9 @@ int beom_sync(beom_handle h, char *errm, int errm_len);
 int beom_set_option(beom_handle h, const char *name, int value);
 
 /* Run all launches of this handle on the caller's HIP stream (e.g. the stream a
- * ghost-row exchange is enqueued on); NULL restores the handle's own stream. */
-int beom_set_stream(beom_handle h, void *hip_stream);
+ * ghost-row exchange is enqueued on).  hip_stream may be NULL = the default stream;
+ * use_own != 0 restores the handle's own stream. */
+int beom_set_stream(beom_handle h, void *hip_stream, int use_own);
 
 /* Per-sweep entry points with the reference routines' meaning; used by parity tests.
  * ilay is 1-based as in Fortran; ilay = 0 means "all layers" (one batched launch).

@@ -270,5 +270,11 @@ def test_profile_start_stop_counts_launches():
     e.profile_start()
     e.step(5, 6, sync=False)
     ms, nl = e.profile_stop()
-    assert nl == [6, 6, 6, 6, 6] and all(m > 0 for m in ms)
+    assert nl == [6, 6, 0, 6, 6]          # fused: no separate viscosity launch
+    assert all(m > 0 for i, m in enumerate(ms) if i != 2)
+    e.set_option("fuse", 0)
+    e.profile_start()
+    e.step(11, 4, sync=False)
+    ms, nl = e.profile_stop()
+    assert nl == [4, 4, 4, 4, 4] and all(m > 0 for m in ms)
     e.close()
