@@ -243,7 +243,7 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_update_mont_all(DevView d) {
 }
 
 // ---- fused sweep: update_mont_rvor_pvor_dive_kine (:2318-2439) + update_viscosity
-//      (:2441-2502) for dense frames.  rvor and dive of a 64 x 8 tile plus a one-cell ring
+//      (:2441-2502) for dense frames.  rvor and dive of a 64 x MV_TY tile plus a one-cell ring
 //      are staged in LDS (double-buffered over layers, one barrier per layer); the Leith
 //      stencil reads them from LDS, and the sweep hands update_u/update_v the products
 //          pcd = v_cc*dive   and   qlr = v_ll*rvor
@@ -253,7 +253,13 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_update_mont_all(DevView d) {
 //      four arrays are stored as well (parity tests; needed when viscosity is not refreshed
 //      every step — then the unfused path runs instead).
 #define MV_TX 64
-#define MV_TY 8
+#ifndef MV_Q
+#define MV_Q 2                         // rows (cells) per thread
+#endif
+#define MV_TY (4 * MV_Q)
+#ifndef MV_UNROLL
+#define MV_UNROLL 4                    // measured: not unrolling the layer loop is 20 % slower
+#endif
 #define MV_LDX (MV_TX + 2 + 1)          // +1 pad column
 #define MV_LDY (MV_TY + 2)
 
@@ -291,13 +297,13 @@ __device__ __forceinline__ void body_mont_visc(const DevView &d, int x0, int y0,
     const int lx = tid & 63, wy = tid >> 6;              // column in tile, wave = row pair
     const int i = x0 + lx;
     const double i_gr = d.i_gr, i_ns = d.i_ns, hs_8 = d.hsal;
-    // own cells: rows y0+wy and y0+wy+4
-    CellDenseT<INT> c[2];
-    bool ok[2];
-    double h[2][NL], hcol[2], fcor[2], h_th[2], h_to[2];
-    int n1[2], n3[2], n5[2], n6[2], n7[2];
+    // own cells: rows y0+wy (+4 per extra cell)
+    CellDenseT<INT> c[MV_Q];
+    bool ok[MV_Q];
+    double hcol[MV_Q], fcor[MV_Q], h_th[MV_Q], h_to[MV_Q];
+    int n1[MV_Q], n3[MV_Q], n5[MV_Q], n6[MV_Q], n7[MV_Q];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < MV_Q; ++q) {
         const int j = y0 + wy + 4 * q;
         ok[q] = (i <= d.L) && (j <= d.M);
         c[q].set_cell(d, ok[q] ? i : 1, ok[q] ? j : 1);
@@ -307,11 +313,9 @@ __device__ __forceinline__ void body_mont_visc(const DevView &d, int x0, int y0,
         h_to[q] = d.has_hto ? d.h_to[c[q].ipnt] : 0.0;
         hcol[q] = 0.0;
 #pragma unroll
-        for (int l = 0; l < NL; ++l) h[q][l] = LL(d.hlay, c[q].ipnt, l + 1);
-#pragma unroll
-        for (int l = 0; l < NL; ++l) hcol[q] = hcol[q] + h[q][l];
+        for (int l = 0; l < NL; ++l) hcol[q] = hcol[q] + LL(d.hlay, c[q].ipnt, l + 1);
     }
-    // halo cell of this thread (threads 0..147): ring of the 66 x 10 region
+    // halo cell of this thread: ring of the (MV_TX+2) x (MV_TY+2) region
     int ha = 0, hb = 0, hr = -1, hc = -1;
     if (tid < MV_TX + 2) { hr = 0; hc = tid; }
     else if (tid < 2 * (MV_TX + 2)) { hr = MV_TY + 1; hc = tid - (MV_TX + 2); }
@@ -319,12 +323,13 @@ __device__ __forceinline__ void body_mont_visc(const DevView &d, int x0, int y0,
     else if (tid < 2 * (MV_TX + 2) + 2 * MV_TY) { hr = 1 + tid - 2 * (MV_TX + 2) - MV_TY; hc = MV_TX + 1; }
     if (hr >= 0) { ha = x0 - 1 + hc; hb = y0 - 1 + hr; }
 
-#pragma unroll
+    // the few re-reads of the cell's own column hit L1/L2
+#pragma unroll MV_UNROLL
     for (int l = 0; l < NL; ++l) {
         const int ilay = l + 1, buf = l & 1;
-        double rv[2], dv[2], u_le[2], u_ri[2], v_bo[2], v_to[2];
+        double rv[MV_Q], dv[MV_Q], u_le[MV_Q], u_ri[MV_Q], v_bo[MV_Q], v_to[MV_Q];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < MV_Q; ++q) {
             rv[q] = 0.0; dv[q] = 0.0; u_le[q] = u_ri[q] = v_bo[q] = v_to[q] = 0.0;
             if (ok[q]) rv_dv_at<INT>(d, c[q], ilay, rv[q], dv[q], u_le[q], u_ri[q], v_bo[q], v_to[q]);
             // The staged entry at a geometric position is what a NEIGHBOUR lookup of that target
@@ -346,7 +351,7 @@ __device__ __forceinline__ void body_mont_visc(const DevView &d, int x0, int y0,
         }
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < MV_Q; ++q) {
             if (!ok[q]) continue;
             const CellDenseT<INT> &cc = c[q];
             const int ipnt = cc.ipnt;
@@ -355,7 +360,7 @@ __device__ __forceinline__ void body_mont_visc(const DevView &d, int x0, int y0,
             const double mk1 = cc.template mk_n_nb<1>(n1[q]), mk3 = cc.template mk_n_nb<3>(n3[q]),
                          mk5 = cc.template mk_n_nb<5>(n5[q]), mk6 = cc.template mk_n_nb<6>(n6[q]),
                          mk7 = cc.template mk_n_nb<7>(n7[q]);
-            const double h0 = h[q][l];
+            const double h0 = LL(d.hlay, ipnt, ilay);
             double mpot = -0.0;
             if (d.ocrp != 0.0) {
                 mpot = h0 + d.hmin * (1.0 - mkn);
@@ -364,8 +369,7 @@ __device__ __forceinline__ void body_mont_visc(const DevView &d, int x0, int y0,
             }
             mpot = mpot - h_to[q];
             const double i_rn = d.i_rn[l];
-#pragma unroll
-            for (int m = 0; m < l; ++m) mpot = mpot - (d.rhon[l] - d.rhon[m]) * i_rn * h[q][m];
+            for (int m = 0; m < l; ++m) mpot = mpot - (d.rhon[l] - d.rhon[m]) * i_rn * LL(d.hlay, ipnt, m + 1);
             if (d.rgld < 0.5) mpot = hcol[q] - h_th[q] + mpot;
             LL(d.mont, ipnt, ilay) = mpot + 0.25 * d.uadv * i_gr
                                           * (u_ri[q] * u_ri[q] + u_le[q] * u_le[q] + v_to[q] * v_to[q] + v_bo[q] * v_bo[q]);
