@@ -27,8 +27,12 @@ sys.path.insert(0, ROOT)
 B_ALG_STEP = 416.0            # algorithmic bytes per cell-layer update (52 FP64 words)
 B_ALG_KERNEL = {              # per sweep, bytes per cell-layer (SURVEY §8d word counts x 8)
     "update_h": 7 * 8, "update_mont": 9 * 8, "update_viscosity": 4 * 8, "update_u": 16 * 8, "update_v": 16 * 8,
+    # fused launches do the work of two reference sweeps: their algorithmic bytes are the sum
+    "update_mont+update_viscosity": (9 + 4) * 8, "update_u+update_v": (16 + 16) * 8,
 }
-KERNEL_ORDER = ("update_h", "update_mont", "update_viscosity", "update_u", "update_v")
+KERNEL_ORDER = ("update_h", "update_mont", "update_viscosity", "update_u", "update_v",
+                "update_mont+update_viscosity", "update_u+update_v")
+NCLS = len(KERNEL_ORDER)
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec (≈6.3 TB/s achievable)
 
 
@@ -125,8 +129,8 @@ def main():
     units_per_step = float(p.ndeg) * p.nlay              # cell-layer updates in one step, whole job
     value = units_per_step * K / elapsed
     # dominant kernel = the longest-running sweep of this run
-    per_launch_ms = [ms[i] / nl[i] if nl[i] else 0.0 for i in range(5)]
-    dom = max(range(5), key=lambda i: ms[i])
+    per_launch_ms = [ms[i] / nl[i] if nl[i] else 0.0 for i in range(NCLS)]
+    dom = max(range(NCLS), key=lambda i: ms[i])
     units_per_launch = units_per_step / world            # one launch covers this rank's slab, all layers
     ach = B_ALG_KERNEL[KERNEL_ORDER[dom]] * units_per_launch / (per_launch_ms[dom] * 1e-3) / 1e9
     roof = {"bound": "hbm", "kernel": KERNEL_ORDER[dom], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -136,7 +140,7 @@ def main():
             "per_kernel": {KERNEL_ORDER[i]: {"avg_ms": per_launch_ms[i], "launches": nl[i],
                                              "alg_GBs": (B_ALG_KERNEL[KERNEL_ORDER[i]] * units_per_launch
                                                          / (per_launch_ms[i] * 1e-3) / 1e9) if nl[i] else None}
-                           for i in range(5)},
+                           for i in range(NCLS) if nl[i]},
             "step_alg_GBs": B_ALG_STEP * value / 1e9, "step_frac": B_ALG_STEP * value / 1e9 / HBM_PEAK_GBS}
     traffic_file = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(traffic_file):

@@ -229,23 +229,26 @@ class Engine:
         ms = (C.c_double * 8)()
         nl = (C.c_int * 8)()
         self._check(self.lib.beom_profile_stop(self.h, ms, nl, self._err, ERRLEN))
-        return list(ms)[:5], list(nl)[:5]
+        return list(ms)[:7], list(nl)[:7]
 
     def field_tensors(self, names=("hlay", "u", "v", "h_u", "h_v")):
         """Zero-copy torch views [nlay, ndeg+1] of the device-resident prognostic fields."""
         import torch
         out = {}
         n1 = self.p.ndeg + 1
+        cache = self.__dict__.setdefault("_tensor_cache", {})
         for k in names:
             ptr, sl, sr, r0 = C.c_void_p(), C.c_int64(), C.c_int64(), C.c_int64()
             self._check(self.lib.beom_device_field(self.h, k.encode(), C.byref(ptr), C.byref(sl),
                                                    C.byref(sr), C.byref(r0)))
             assert sl.value == n1
-
-            class _Iface:
-                __cuda_array_interface__ = {"shape": (self.p.nlay, n1), "typestr": "<f8",
-                                            "data": (ptr.value, False), "version": 3}
-            out[k] = torch.as_tensor(_Iface(), device=torch.device("cuda", self.device))
+            t = cache.get(ptr.value)          # the fused sweeps ping-pong buffers: key by address
+            if t is None:
+                class _Iface:
+                    __cuda_array_interface__ = {"shape": (self.p.nlay, n1), "typestr": "<f8",
+                                                "data": (ptr.value, False), "version": 3}
+                t = cache[ptr.value] = torch.as_tensor(_Iface(), device=torch.device("cuda", self.device))
+            out[k] = t
         return out
 
     def profile_steps(self, tstp_first: int, nsteps: int, tres: float = 0.0):
@@ -255,7 +258,7 @@ class Engine:
         self._check(self.lib.beom_profile_steps(self.h, tstp_first, nsteps, tres, float(p.dtd8),
                                                 float(p.dt_r), float(p.rsta), p.n_3d, ms, nl,
                                                 self._err, ERRLEN))
-        return list(ms)[:5], list(nl)[:5]
+        return list(ms)[:7], list(nl)[:7]
 
     @property
     def is_dense(self) -> bool:

@@ -26,7 +26,8 @@ struct DevView {
     // prognostic
     double *hlay, *u, *v, *h_u, *h_v;
     double *rs[2];                // rs[0] = rs_h(1,..) older, rs[1] = rs_h(2,..) newer
-    double *dmx[3], *dmy[3];      // [0] oldest .. [2] newest
+    double *dmx[4], *dmy[4];      // [0] oldest .. [2] newest; [3] spare (fused U+V sweep writes there)
+    double *u_alt, *v_alt, *hu_alt, *hv_alt;   // ping-pong partners of u, v, h_u, h_v (fused U+V sweep)
     double *v_cc, *v_ll, *tt3d, *tb3d, *tu3d;
     // per-layer diagnostics (0:ndeg, nlay)
     double *mont, *rvor, *pvor, *dive, *d2hx, *d2hy;

@@ -49,6 +49,7 @@ struct beom_engine {
     dim3 grid_cells0, grid_cells_layers_flat;
     bool wind = false, bot = false, top = false;
     bool fuse = true;                  // dense frames: Montgomery+Leith in one sweep (k_mont_visc)
+    bool fuse_uv = true;               // dense frames: update_u + update_v in one sweep (k_uv_fused)
     char last_err[512] = {0};
 };
 
@@ -202,6 +203,7 @@ int beom_create(const beom_params *prm, int device, const int32_t *neig, const i
     d.has_hto = any_nonzero(h_to, n1);
     d.keep_diag = 0;
     E->fuse = getenv("BEOM_NO_FUSE") == nullptr;
+    E->fuse_uv = getenv("BEOM_NO_FUSE") == nullptr && getenv("BEOM_NO_FUSE_UV") == nullptr;
     E->wind = false;
     if (taus) for (size_t i = 0; i < 2 * n1; ++i) if (std::fabs(taus[i]) > 1.e-7) { E->wind = true; break; }   // :1945
     E->bot = prm->bdrg > 1.e-7;                                                                                  // :1969
@@ -213,6 +215,10 @@ int beom_create(const beom_params *prm, int device, const int32_t *neig, const i
     AL(rs[0], nl * n1) AL(rs[1], nl * n1)
     AL(dmx[0], nl * n1) AL(dmx[1], nl * n1) AL(dmx[2], nl * n1)
     AL(dmy[0], nl * n1) AL(dmy[1], nl * n1) AL(dmy[2], nl * n1)
+    if (E->dense) {            // partners for the fused U+V sweep
+        AL(dmx[3], nl * n1) AL(dmy[3], nl * n1)
+        AL(u_alt, nl * n1) AL(v_alt, nl * n1) AL(hu_alt, nl * n1) AL(hv_alt, nl * n1)
+    }
     AL(v_cc, nl * n1) AL(v_ll, nl * n1)
     AL(tt3d, 2 * nl * n1) AL(tb3d, 2 * nl * n1) AL(tu3d, 2 * nl * n1)
     AL(pcd, nl * n1) AL(qlr, nl * n1)
@@ -365,7 +371,9 @@ int beom_sync(beom_handle E, char *errm, int errm_len) {
 
 // ---- launches -------------------------------------------------------------------------
 static inline void rot2(double *(&a)[2]) { double *t = a[0]; a[0] = a[1]; a[1] = t; }
-static inline void rot3(double *(&a)[3]) { double *t = a[0]; a[0] = a[1]; a[1] = a[2]; a[2] = t; }
+static inline void rot3(double *(&a)[4]) { double *t = a[0]; a[0] = a[1]; a[1] = a[2]; a[2] = t; }
+static inline void rot4(double *(&a)[4]) { double *t = a[0]; a[0] = a[1]; a[1] = a[2]; a[2] = a[3]; a[3] = t; }
+static inline void swp(double *&a, double *&b) { double *t = a; a = b; b = t; }
 
 // LAUNCH(kernel-template-name, extra template args..., nz, args...) picks the cell context.
 #define LAUNCH_CTX(KERNEL_G, KERNEL_D, nz, ...)                                                            \
@@ -423,6 +431,20 @@ static bool launch_mont_visc(beom_engine *E) {
         default: return false;
     }
 }
+// fused U+V sweep (dense frames): first_x = update_u first (even tstp)
+static void launch_uv_fused(beom_engine *E, bool first_x, bool prod, double gene, double ramp, double ctim) {
+    const dim3 g = uv_fused_grid(E->d), b(BEOM_BLOCK);
+    DevView &d = E->d;
+    if (first_x) {
+        if (prod) hipLaunchKernelGGL((k_uv_fused<true, true>), g, b, 0, E->stream, d, gene, ramp, ctim);
+        else hipLaunchKernelGGL((k_uv_fused<true, false>), g, b, 0, E->stream, d, gene, ramp, ctim);
+        swp(d.u, d.u_alt); rot4(d.dmx); swp(d.h_v, d.hv_alt); rot3(d.dmy);
+    } else {
+        if (prod) hipLaunchKernelGGL((k_uv_fused<false, true>), g, b, 0, E->stream, d, gene, ramp, ctim);
+        else hipLaunchKernelGGL((k_uv_fused<false, false>), g, b, 0, E->stream, d, gene, ramp, ctim);
+        swp(d.v, d.v_alt); rot4(d.dmy); swp(d.h_u, d.hu_alt); rot3(d.dmx);
+    }
+}
 static bool can_fuse(const beom_engine *E, int n_3d) {
     // every step must refresh the viscosity (else v_cc/v_ll have to persist): dvis > 1e-3 and n_3d = 1 (:2268)
     const int nl = E->d.nlay;
@@ -454,7 +476,7 @@ int beom_distribute_stress(beom_handle E) { NEED(E); launch_stress(E); return 0;
 }  // extern "C"
 
 // Per-step scalars of integrate_time (private_mod.f95:1858-1901).
-struct StepScalars { double ctim, ramp, gene; bool first3, upst, stress, fused; };
+struct StepScalars { double ctim, ramp, gene; bool first3, upst, stress, fused, fused_uv; };
 static StepScalars step_scalars(const beom_engine *E, int tstp, double tres, double dtd8, double dt_r,
                                 double rsta, int n_3d) {
     StepScalars s;
@@ -473,6 +495,7 @@ static StepScalars step_scalars(const beom_engine *E, int tstp, double tres, dou
     }
     s.gene = s.first3 ? 0.0 : E->P.g_fb;                           // :1859,1877
     s.fused = can_fuse(E, n_3d);
+    s.fused_uv = E->dense && E->fuse_uv;
     return s;
 }
 
@@ -490,7 +513,7 @@ static void one_step(beom_engine *E, int tstp, const StepScalars &s) {
     if (s.first3) launch_rebuild(E);                               // :2166-2177
     if (T) T->begin(0);
     launch_h(E, s.gene, s.ramp, s.ctim);                           // :2181,2259
-    if (T) { T->end(); T->begin(1); }
+    if (T) { T->end(); T->begin(s.fused ? 5 : 1); }
     const bool prod = s.fused && launch_mont_visc(E);              // :2187-2188, 2266-2269 in one sweep
     if (!prod) launch_mont(E, 0);
     if (T) T->end();
@@ -499,7 +522,12 @@ static void one_step(beom_engine *E, int tstp, const StepScalars &s) {
         launch_visc(E, 0);
         if (T) T->end();
     }
-    if (tstp % 2 == 0) {                                           // :2193-2199,2276-2282
+    const bool u_first = tstp % 2 == 0;                            // :2193-2199,2276-2282
+    if (s.fused_uv) {
+        if (T) T->begin(6);
+        launch_uv_fused(E, u_first, prod, s.gene, s.ramp, s.ctim);
+        if (T) T->end();
+    } else if (u_first) {
         if (T) T->begin(3);
         launch_uv<true>(E, 0, s.gene, s.ramp, s.ctim, prod);
         if (T) { T->end(); T->begin(4); }
@@ -541,7 +569,7 @@ int beom_profile_stop(beom_handle E, double *ms, int *launches, char *errm, int 
     HIP_TRY(hipSetDevice(E->device));
     HIP_TRY(hipStreamSynchronize(E->stream));
     StepTimer &T = *E->timer;
-    for (int c = 0; c < 5; ++c) { ms[c] = 0.0; launches[c] = 0; }
+    for (int c = 0; c < 7; ++c) { ms[c] = 0.0; launches[c] = 0; }
     for (size_t k = 0; k < T.cls.size(); ++k) {
         float t = 0.f;
         (void)hipEventElapsedTime(&t, T.ev[2 * k], T.ev[2 * k + 1]);
@@ -566,7 +594,9 @@ int beom_profile_steps(beom_handle E, int tstp_first, int nsteps, double tres, d
 
 int beom_set_option(beom_handle E, const char *name, int value) {
     if (!E || !name) return -1;
-    if (!strcmp(name, "fuse")) E->fuse = value != 0;
+    if (!strcmp(name, "fuse")) { E->fuse = value != 0; E->fuse_uv = value != 0; }
+    else if (!strcmp(name, "fuse_mont_visc")) E->fuse = value != 0;
+    else if (!strcmp(name, "fuse_uv")) E->fuse_uv = value != 0;
     else if (!strcmp(name, "keep_diag")) E->d.keep_diag = value != 0;
     else return -3;
     return 0;

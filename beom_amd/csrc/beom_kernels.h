@@ -469,20 +469,29 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_update_visc(DevView d, int ilay_
 
 // ---- update_u (XDIR=true, private_mod.f95:1422-1503) and update_v (XDIR=false,
 //      :1505-1591).  The two routines are mirror images: W<->S, N<->E, NW<->SE. -------
-template <bool XDIR, bool PROD, class C>
-__device__ __forceinline__ void body_update_uv(const C &c, const DevView &d, int ilay_only, double gene,
-                                                          double ramp, double ctim, int copy_hist) {
+// Where one momentum update reads and writes its prognostic data.  The unfused sweeps update
+// in place (vel_out = vel_in, dm_out = oldest history level); the fused U+V sweep writes the
+// FIRST component out of place because other workgroups re-evaluate it on their halo cells.
+struct UVio {
+    const double *vel_in; double *vel_out;      // u or v
+    double *hp_out;                             // h_u or h_v (transport of THIS component)
+    const double *dm0, *dm1, *dm2;              // history, oldest .. newest
+    double *dm_out;                             // receives dmd4
+};
+
+// One cell of update_u (XDIR) / update_v.  q0,qb,qa,qd = transport of the OTHER component at
+// self, cb, ca, cd (u: W,N,NW; v: S,E,SE) — from global memory, or from the LDS tile in the
+// fused sweep.  STORE=false evaluates without any global store (halo cells) and returns the
+// new transport of this component.
+template <bool XDIR, bool PROD, bool STORE, class C>
+__device__ __forceinline__ double uv_core(const C &c, const DevView &d, int ilay, double gene, double ramp,
+                                          double ctim, int copy_hist, const UVio &io,
+                                          double q0, double qb, double qa, double qd) {
     const int ipnt = c.ipnt;
-    const int ilay = ilay_only ? ilay_only : (int)blockIdx.y + 1;
-    // u: cb = W(5), ca = N(3), cd = NW(4);   v: cb = S(7), ca = E(1), cd = SE(8)
+    // u: cb = W(5), ca = N(3);   v: cb = S(7), ca = E(1)
     const int cb = XDIR ? c.template nb<5>() : c.template nb<7>();
     const int ca = XDIR ? c.template nb<3>() : c.template nb<1>();
-    const int cd = XDIR ? c.template nb<4>() : c.template nb<8>();
-    double *vel = XDIR ? d.u : d.v;
-    const double *hq = XDIR ? d.h_v : d.h_u;       // the transport of the OTHER component
-    double *hp = XDIR ? d.h_u : d.h_v;
     const double *d2h = XDIR ? d.d2hx : d.d2hy;
-    double *const *dm = XDIR ? d.dmx : d.dmy;
     constexpr int IV = XDIR ? 2 : 3;               // ix_u / ix_v
     constexpr int ID = XDIR ? 1 : 2;               // stress component of this direction
     constexpr int IO = XDIR ? 2 : 1;               // the other one (Ekman term of ufor/vfor)
@@ -490,10 +499,9 @@ __device__ __forceinline__ void body_update_uv(const C &c, const DevView &d, int
     const double mask = XDIR ? c.mk_u() : c.mk_v();
     const double hcen = XDIR ? (LL(d.hlay, cb, ilay) + LL(d.hlay, ipnt, ilay)) / (1.0 + mask)
                              : (LL(d.hlay, ipnt, ilay) + LL(d.hlay, cb, ilay)) / (1.0 + mask);
-    double vold = LL(vel, ipnt, ilay);
+    double vold = LL(io.vel_in, ipnt, ilay);
     const double dmd4 = (LL(d.mont, cb, ilay) - LL(d.mont, ipnt, ilay)) * i_dl * d.grav * mask;
     const double pv0 = LL(d.pvor, ipnt, ilay), pva = LL(d.pvor, ca, ilay);
-    const double q0 = LL(hq, ipnt, ilay), qb = LL(hq, cb, ilay), qa = LL(hq, ca, ilay), qd = LL(hq, cd, ilay);
     double rhsi = dmd4 * (1.0 - gene);
     if (XDIR) rhsi = rhsi + 0.25 * pv0 * (q0 + qb) + 0.25 * pva * (qa + qd);
     else      rhsi = rhsi - 0.25 * pv0 * (q0 + qb) - 0.25 * pva * (qa + qd);
@@ -508,14 +516,14 @@ __device__ __forceinline__ void body_update_uv(const C &c, const DevView &d, int
     // gene = 0 (steps 1-3, g_fb = 0): the term is (finite)*0 = +-0 and only matters for the sign of
     // an exactly-zero rhsi; fetch the history on those (rare) lanes only.
     if (gene != 0.0 || rhsi == 0.0) {
-        rhsi = rhsi + (d.del1 * dmd4 + d.del2 * LL(dm[2], ipnt, ilay) + d.gamm * LL(dm[1], ipnt, ilay)
-                       + d.epsi * LL(dm[0], ipnt, ilay)) * gene;
+        rhsi = rhsi + (d.del1 * dmd4 + d.del2 * LL(io.dm2, ipnt, ilay) + d.gamm * LL(io.dm1, ipnt, ilay)
+                       + d.epsi * LL(io.dm0, ipnt, ilay)) * gene;
     }
     if (PROD) {       // products staged by k_mont_visc: pcd = v_cc*dive, qlr = v_ll*rvor
         const double p0 = LL(d.pcd, ipnt, ilay), pb = LL(d.pcd, cb, ilay);
-        const double q0 = LL(d.qlr, ipnt, ilay), qa = LL(d.qlr, ca, ilay);
-        if (XDIR) rhsi = rhsi + (p0 - pb) * i_dl - (qa - q0) * i_dl;
-        else      rhsi = rhsi + (p0 - pb) * i_dl + (qa - q0) * i_dl;
+        const double l0 = LL(d.qlr, ipnt, ilay), la = LL(d.qlr, ca, ilay);
+        if (XDIR) rhsi = rhsi + (p0 - pb) * i_dl - (la - l0) * i_dl;
+        else      rhsi = rhsi + (p0 - pb) * i_dl + (la - l0) * i_dl;
     } else {
         const double vc0 = LL(d.v_cc, ipnt, ilay), vcb = LL(d.v_cc, cb, ilay);
         const double vl0 = LL(d.v_ll, ipnt, ilay), vla = LL(d.v_ll, ca, ilay);
@@ -542,18 +550,36 @@ __device__ __forceinline__ void body_update_uv(const C &c, const DevView &d, int
         const double ng = d.has_nudg ? NUDG_(ipnt, IV) : 0.0;
         vold = vfor * ng + vold * (1.0 - ng);
     }
-    LL(vel, ipnt, ilay) = vold;
-    if (d.rgld < 0.5)
-        LL(hp, ipnt, ilay) = 0.5 * (vold + fabs(vold)) * (hcen - 0.16667 * LL(d2h, cb, ilay))
-                           + 0.5 * (vold - fabs(vold)) * (hcen - 0.16667 * LL(d2h, ipnt, ilay));
-    if (copy_hist) {
-        const double m2 = LL(dm[1], ipnt, ilay), m3 = LL(dm[2], ipnt, ilay);
-        LL(dm[0], ipnt, ilay) = m2;
-        LL(dm[1], ipnt, ilay) = m3;
-        LL(dm[2], ipnt, ilay) = dmd4;
-    } else {
-        LL(dm[0], ipnt, ilay) = dmd4;          // host rotates (dm0,dm1,dm2) <- (dm1,dm2,dm0)
+    const double hnew = 0.5 * (vold + fabs(vold)) * (hcen - 0.16667 * LL(d2h, cb, ilay))
+                      + 0.5 * (vold - fabs(vold)) * (hcen - 0.16667 * LL(d2h, ipnt, ilay));   // rgld = 0 (:1491,1577)
+    if (STORE) {
+        LL(io.vel_out, ipnt, ilay) = vold;
+        LL(io.hp_out, ipnt, ilay) = hnew;
+        if (copy_hist) {                       // single-layer entry points: shift like the reference
+            const double m2 = LL(io.dm1, ipnt, ilay), m3 = LL(io.dm2, ipnt, ilay);
+            LL(const_cast<double *>(io.dm0), ipnt, ilay) = m2;
+            LL(const_cast<double *>(io.dm1), ipnt, ilay) = m3;
+            LL(const_cast<double *>(io.dm2), ipnt, ilay) = dmd4;
+        } else {
+            LL(io.dm_out, ipnt, ilay) = dmd4;  // the host rotates the history pointers afterwards
+        }
     }
+    return hnew;
+}
+
+template <bool XDIR, bool PROD, class C>
+__device__ __forceinline__ void body_update_uv(const C &c, const DevView &d, int ilay_only, double gene,
+                                               double ramp, double ctim, int copy_hist) {
+    const int ipnt = c.ipnt;
+    const int ilay = ilay_only ? ilay_only : (int)blockIdx.y + 1;
+    const int cb = XDIR ? c.template nb<5>() : c.template nb<7>();
+    const int ca = XDIR ? c.template nb<3>() : c.template nb<1>();
+    const int cd = XDIR ? c.template nb<4>() : c.template nb<8>();
+    const double *hq = XDIR ? d.h_v : d.h_u;       // the transport of the OTHER component
+    double *const *dm = XDIR ? d.dmx : d.dmy;
+    const UVio io{XDIR ? d.u : d.v, XDIR ? d.u : d.v, XDIR ? d.h_u : d.h_v, dm[0], dm[1], dm[2], dm[0]};
+    uv_core<XDIR, PROD, true>(c, d, ilay, gene, ramp, ctim, copy_hist, io,
+                              LL(hq, ipnt, ilay), LL(hq, cb, ilay), LL(hq, ca, ilay), LL(hq, cd, ilay));
 }
 template <class CTX, bool XDIR, bool PROD = false>
 __global__ __launch_bounds__(BEOM_BLOCK) void k_update_uv(DevView d, int ilay_only, double gene,
@@ -562,6 +588,136 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_update_uv(DevView d, int ilay_on
     if (!c.init(d)) return;
     if (c.wave_is_interior()) body_update_uv<XDIR, PROD>(c.as_interior(), d, ilay_only, gene, ramp, ctim, copy_hist);
     else body_update_uv<XDIR, PROD>(c, d, ilay_only, gene, ramp, ctim, copy_hist);
+}
+
+// ---- fused momentum sweep for dense frames: update_u and update_v (:1422-1591) of one
+//      time step in ONE launch, in the order the step's parity asks for (:2276-2282).
+//      The second update needs the first one's NEW transport at three neighbours
+//      (v: h_u at E,S,SE :1531-1534; u: h_v at N,NW,W :1446-1449).  A workgroup evaluates the
+//      first update on its 64 x 8 tile plus the one-cell row/column the second needs (73 extra
+//      cells, 14 %), keeps the new transport in LDS, and runs the second update from it; its
+//      own re-reads of hlay, mont, pvor, pcd, qlr hit L1/L2.  Because halo cells are evaluated
+//      by a workgroup that does not own them, everything the FIRST update reads of a cell must
+//      stay untouched during the launch: its velocity and newest history level go to spare
+//      buffers (pointer swap afterwards), and the SECOND update's transport is written out of
+//      place as well (the first update of other workgroups still reads the old one).
+//      Algorithmic traffic: 22 words per cell-layer instead of 14 + 14.
+#define UV_TX 64
+#define UV_Q 2
+#define UV_TY (4 * UV_Q)
+#define UV_LDX (UV_TX + 1 + 1)
+
+template <bool FIRST_X, bool PROD, bool STORE, bool INT>
+__device__ __forceinline__ double uv_first_eval(const DevView &d, const CellDenseT<INT> &c, int ilay, double gene,
+                                                double ramp, double ctim) {
+    const int ipnt = c.ipnt;
+    const int cb = FIRST_X ? c.template nb<5>() : c.template nb<7>();
+    const int ca = FIRST_X ? c.template nb<3>() : c.template nb<1>();
+    const int cd = FIRST_X ? c.template nb<4>() : c.template nb<8>();
+    const double *hq = FIRST_X ? d.h_v : d.h_u;
+    double *const *dm = FIRST_X ? d.dmx : d.dmy;
+    const UVio io{FIRST_X ? d.u : d.v, FIRST_X ? d.u_alt : d.v_alt, FIRST_X ? d.h_u : d.h_v,
+                  dm[0], dm[1], dm[2], dm[3]};
+    return uv_core<FIRST_X, PROD, STORE>(c, d, ilay, gene, ramp, ctim, 0, io,
+                                         LL(hq, ipnt, ilay), LL(hq, cb, ilay), LL(hq, ca, ilay), LL(hq, cd, ilay));
+}
+
+// new first-component transport seen by a NEIGHBOUR lookup of the local target (a, b)
+template <bool FIRST_X, bool PROD, bool INT>
+__device__ __forceinline__ double uv_first_halo(const DevView &d, int a, int b, int ilay, double gene,
+                                                double ramp, double ctim) {
+    if (!INT) {
+        if (d.xper) { if (a == 0) a = d.L - 1; else if (a == d.L) a = 1; }
+        if (d.yper && !d.slab) { if (b == 0) b = d.M - 1; else if (b == d.M) b = 1; }
+        if (a < 1 || a > d.L || b < 1 || b > d.M) return 0.0;      // sentinel: h_u(0) = h_v(0) = 0
+    }
+    CellDenseT<INT> h;
+    h.set_cell(d, a, b);
+    return uv_first_eval<FIRST_X, PROD, false, INT>(d, h, ilay, gene, ramp, ctim);
+}
+
+template <bool FIRST_X, bool PROD, bool INT>
+__device__ __forceinline__ void body_uv_fused(const DevView &d, int x0, int y0, int ilay, double gene,
+                                              double ramp, double ctim, double (*s_h)[UV_LDX]) {
+    const int tid = threadIdx.x;
+    const int lx = tid & 63, wy = tid >> 6;
+    const int i = x0 + lx;
+    // LDS coordinates: FIRST_X  -> rows y0-1 .. y0+TY-1, cols x0 .. x0+TX   (own cell at [r+1][lx])
+    //                  !FIRST_X -> rows y0 .. y0+TY,     cols x0-1 .. x0+TX-1 (own cell at [r][lx+1])
+    constexpr int ROFF = FIRST_X ? 1 : 0, COFF = FIRST_X ? 0 : 1;
+    CellDenseT<INT> c[UV_Q];
+    bool ok[UV_Q];
+#pragma unroll
+    for (int q = 0; q < UV_Q; ++q) {
+        const int r = wy + 4 * q, j = y0 + r;
+        ok[q] = (i <= d.L) && (j <= d.M);
+        c[q].set_cell(d, ok[q] ? i : 1, ok[q] ? j : 1);
+        double hnew = 0.0;
+        if (ok[q]) {
+            hnew = uv_first_eval<FIRST_X, PROD, true, INT>(d, c[q], ilay, gene, ramp, ctim);
+            if (!INT) {     // orphan column/row are wrap TARGETS: stage what a neighbour lookup returns
+                if ((d.xper && i == d.L) || (d.yper && !d.slab && j == d.M))
+                    hnew = uv_first_halo<FIRST_X, PROD, INT>(d, i, j, ilay, gene, ramp, ctim);
+            }
+        }
+        s_h[r + ROFF][lx + COFF] = hnew;
+    }
+    // ring cells: one row (65) + one column (UV_TY)
+    {
+        int a = 0, b = 0, rr = -1, cc = -1;
+        if (tid <= UV_TX) {                       // the extra row
+            rr = FIRST_X ? 0 : UV_TY; cc = tid;
+        } else if (tid <= UV_TX + UV_TY) {        // the extra column
+            rr = (tid - UV_TX - 1) + ROFF; cc = FIRST_X ? UV_TX : 0;
+        }
+        if (rr >= 0) {
+            a = (FIRST_X ? x0 : x0 - 1) + cc;
+            b = (FIRST_X ? y0 - 1 : y0) + rr;
+            s_h[rr][cc] = uv_first_halo<FIRST_X, PROD, INT>(d, a, b, ilay, gene, ramp, ctim);
+        }
+    }
+    __syncthreads();
+    // second component, transport of the first from LDS
+    double *const *dm = FIRST_X ? d.dmy : d.dmx;
+    const UVio io{FIRST_X ? d.v : d.u, FIRST_X ? d.v : d.u, FIRST_X ? d.hv_alt : d.hu_alt,
+                  dm[0], dm[1], dm[2], dm[0]};
+#pragma unroll
+    for (int q = 0; q < UV_Q; ++q) {
+        if (!ok[q]) continue;
+        const int r = wy + 4 * q;
+        double q0, qb, qa, qd;
+        if (FIRST_X) {   // v: self, S, E, SE of h_u
+            q0 = s_h[r + 1][lx]; qb = s_h[r][lx]; qa = s_h[r + 1][lx + 1]; qd = s_h[r][lx + 1];
+        } else {         // u: self, W, N, NW of h_v
+            q0 = s_h[r][lx + 1]; qb = s_h[r][lx]; qa = s_h[r + 1][lx + 1]; qd = s_h[r + 1][lx];
+        }
+        uv_core<!FIRST_X, PROD, true>(c[q], d, ilay, gene, ramp, ctim, 0, io, q0, qb, qa, qd);
+    }
+}
+
+template <bool FIRST_X, bool PROD>
+__global__ __launch_bounds__(BEOM_BLOCK) void k_uv_fused(DevView d, double gene, double ramp, double ctim) {
+    __shared__ double s_h[UV_TY + 1][UV_LDX];
+    const int gx = (d.L + UV_TX - 1) / UV_TX;
+    const int gy = (d.M + UV_TY - 1) / UV_TY;
+    const int rpx = (gy + 7) / 8;
+    const int b = blockIdx.x;
+    const int xcd = b & 7, k = b >> 3;
+    const int rib = k / gx, ch = k - rib * gx;
+    const int ty = xcd * rpx + rib;
+    if (ty >= gy) return;
+    const int x0 = ch * UV_TX + 1, y0 = ty * UV_TY + 1;
+    const int ilay = blockIdx.y + 1;
+    const bool interior = x0 - 1 >= 2 && x0 + UV_TX <= d.L - 2 && y0 - 1 >= 2 && y0 + UV_TY <= d.M - 2
+                          && y0 - 1 + d.joff >= 2 && y0 + UV_TY + d.joff <= d.Mg - 2;
+    if (interior) body_uv_fused<FIRST_X, PROD, true>(d, x0, y0, ilay, gene, ramp, ctim, s_h);
+    else body_uv_fused<FIRST_X, PROD, false>(d, x0, y0, ilay, gene, ramp, ctim, s_h);
+}
+static inline dim3 uv_fused_grid(const DevView &d) {
+    const int gx = (d.L + UV_TX - 1) / UV_TX;
+    const int gy = (d.M + UV_TY - 1) / UV_TY;
+    const int rpx = (gy + 7) / 8;
+    return dim3((unsigned)(8 * rpx * gx), (unsigned)d.nlay, 1);
 }
 
 // ---- distribute_stress, private_mod.f95:1921-2149 -----------------------------------

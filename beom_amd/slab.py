@@ -136,8 +136,7 @@ class SlabRunner:
         self.g = geom
         self.nlay = nlay
         self.dist = dist
-        self.t = engine.field_tensors(EXCHANGED)
-        ref = self.t["hlay"]
+        ref = engine.field_tensors(EXCHANGED)["hlay"]
         G = GHOST
         n = len(EXCHANGED) * nlay * G * geom.L
         mk = lambda: torch.empty(n, dtype=ref.dtype, device=ref.device)
@@ -179,20 +178,27 @@ class SlabRunner:
                 "backend": "torch.distributed P2P (RCCL)"}
 
     # -- exchange -----------------------------------------------------------------------
+    @property
+    def t(self):
+        # the engine may ping-pong its buffers between steps: always ask for the live views
+        return self.engine.field_tensors(EXCHANGED)
+
     def _pack(self, buf, rng):
         a, b = rng
         k = 0
+        t = self.t
         m = (b - a) * self.nlay
         for name in EXCHANGED:
-            buf[k:k + m].view(self.nlay, b - a).copy_(self.t[name][:, a:b])
+            buf[k:k + m].view(self.nlay, b - a).copy_(t[name][:, a:b])
             k += m
 
     def _unpack(self, buf, rng):
         a, b = rng
         k = 0
+        t = self.t
         m = (b - a) * self.nlay
         for name in EXCHANGED:
-            self.t[name][:, a:b].copy_(buf[k:k + m].view(self.nlay, b - a))
+            t[name][:, a:b].copy_(buf[k:k + m].view(self.nlay, b - a))
             k += m
 
     def pack_all(self):

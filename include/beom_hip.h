@@ -129,11 +129,14 @@ int beom_step(beom_handle h, int tstp_first, int nsteps,
 
 int beom_sync(beom_handle h, char *errm, int errm_len);
 
-/* Options: "fuse" (default 1; 0 = always five separate sweeps) — on dense frames with the
- * Leith viscosity refreshed every step (dvis > 1e-3, n_3d = 1) update_mont... and
- * update_viscosity run as ONE sweep that hands update_u/v the products v_cc*dive and
- * v_ll*rvor; v_cc, v_ll, rvor, dive are then kept up to date only with "keep_diag" = 1
- * (default 0).  Returns -3 for an unknown name. */
+/* Options (dense frames only; results are bit-identical either way):
+ *  "fuse_mont_visc" (default 1): with the Leith viscosity refreshed every step (dvis > 1e-3,
+ *      n_3d = 1) update_mont... and update_viscosity run as ONE sweep that hands update_u/v
+ *      the products v_cc*dive and v_ll*rvor; v_cc, v_ll, rvor, dive are then kept up to date
+ *      only with "keep_diag" = 1 (default 0).
+ *  "fuse_uv" (default 1): update_u and update_v of a step run as ONE sweep.
+ *  "fuse": sets both.  0 = always five separate sweeps.
+ * Returns -3 for an unknown name. */
 int beom_set_option(beom_handle h, const char *name, int value);
 
 /* Run all launches of this handle on the caller's HIP stream (e.g. the stream a
@@ -162,8 +165,9 @@ int beom_device_field(beom_handle h, const char *name, void **dptr,
 int beom_is_dense(beom_handle h);
 /* Per-kernel device time, measured with HIP events on the handle's stream around every
  * sweep launched by beom_step between start and stop (no host synchronisation in
- * between): ms[0..4] = update_h, update_mont, update_viscosity, update_u, update_v
- * (sums over launches), launches[0..4] = number of launches in each class. */
+ * between): ms[0..6] = update_h, update_mont, update_viscosity, update_u, update_v,
+ * fused mont+viscosity, fused u+v (sums over launches), launches[0..6] = number of
+ * launches in each class.  Both arrays need 8 entries. */
 int beom_profile_start(beom_handle h);
 int beom_profile_stop(beom_handle h, double *ms, int *launches, char *errm, int errm_len);
 /* = beom_profile_start; beom_step(...); beom_profile_stop. */

@@ -28,19 +28,22 @@ def _check(a, b, exact, what):
         assert maxrel(a, b) <= COS_TOL, (what, maxrel(a, b))
 
 
-MODES = {          # name: (dense_hint, fuse, keep_diag)
-    "gather": (0, 1, 0),
-    "dense_unfused": (1, 0, 0),
-    "dense_fused_keepdiag": (1, 1, 1),
-    "dense_fused": (1, 1, 0),          # the production default
+MODES = {          # name: (dense_hint, fuse_mont_visc, fuse_uv, keep_diag)
+    "gather": (0, 1, 1, 0),
+    "dense_unfused": (1, 0, 0, 0),
+    "dense_fused_keepdiag": (1, 1, 1, 1),
+    "dense_fuse_mv_only": (1, 1, 0, 0),
+    "dense_fuse_uv_only": (1, 0, 1, 0),
+    "dense_fused": (1, 1, 1, 0),       # the production default
 }
 PROGNOSTIC = ("hlay", "u", "v", "h_u", "h_v", "rs_h", "dmdx", "dmdy", "tt3d", "tb3d", "tu3d")
 
 
 def _engine(f, variant=0, mode="dense_fused", **kw):
-    dh, fuse, keep = MODES[mode]
+    dh, fmv, fuv, keep = MODES[mode]
     e = capi.Engine(f, variant=variant, dense_hint=dh, **kw)
-    e.set_option("fuse", fuse)
+    e.set_option("fuse_mont_visc", fmv)
+    e.set_option("fuse_uv", fuv)
     e.set_option("keep_diag", keep)
     return e
 
@@ -58,7 +61,7 @@ def test_step_matches_reference_golden(name, mode):
     g = Golden(name)
     e = _engine(_fields(g), variant=g.variant, mode=mode)
     exact = not g.uses_cos()
-    lossy = mode == "dense_fused" and _fusion_active(g, e)
+    lossy = mode in ("dense_fused", "dense_fuse_mv_only") and _fusion_active(g, e)
     t = 0
     for tgt in GOLDEN_STEPS:
         e.step(t + 1, tgt - t)
@@ -197,7 +200,7 @@ def test_dense_interior_waves_match_oracle_and_gather(case):
         x.step(1, 12)
     ref_sc = engines["gather"].download_scratch()
     for m, e in engines.items():
-        lossy = m == "dense_fused" and float(p.dvis) > 1e-3 and p.n_3d == 1
+        lossy = m in ("dense_fused", "dense_fuse_mv_only") and float(p.dvis) > 1e-3 and p.n_3d == 1
         st = e.download()
         for k in (PROGNOSTIC if lossy else STATE):
             assert same(st[k], o.state()[k]), (case, m, k, maxrel(st[k], o.state()[k]))
@@ -270,11 +273,11 @@ def test_profile_start_stop_counts_launches():
     e.profile_start()
     e.step(5, 6, sync=False)
     ms, nl = e.profile_stop()
-    assert nl == [6, 6, 0, 6, 6]          # fused: no separate viscosity launch
-    assert all(m > 0 for i, m in enumerate(ms) if i != 2)
+    assert nl == [6, 0, 0, 0, 0, 6, 6]    # fused: H, mont+visc, u+v
+    assert all(m > 0 for i, m in enumerate(ms) if nl[i])
     e.set_option("fuse", 0)
     e.profile_start()
     e.step(11, 4, sync=False)
     ms, nl = e.profile_stop()
-    assert nl == [4, 4, 4, 4, 4] and all(m > 0 for m in ms)
+    assert nl == [4, 4, 4, 4, 4, 0, 0] and all(m > 0 for m in ms[:5])
     e.close()
