@@ -18,10 +18,10 @@ import glob
 import json
 import sys
 
-CLASS = {"k_update_h": "update_h", "k_update_mont": "update_mont", "k_update_visc": "update_viscosity",
+CLASS = {"k_update_h": "update_h", "k_update_mont": "update_mont",  # first match wins: order matters "k_update_visc": "update_viscosity",
          "k_update_uv<CellDenseT<false>, true>": "update_u", "k_update_uv<CellDenseT<false>, false>": "update_v",
          "k_update_uv<CellGather, true>": "update_u", "k_update_uv<CellGather, false>": "update_v",
-         "k_step_fused": "step_fused"}
+         "k_mont_visc": "update_mont+update_viscosity", "k_uv_fused": "update_u+update_v"}
 
 
 def classify(name):
