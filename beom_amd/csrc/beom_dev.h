@@ -34,6 +34,7 @@ struct DevView {
     // fused Montgomery+Leith sweep: products v_cc*dive and v_ll*rvor (0:ndeg, nlay)
     double *pcd, *qlr;
     int keep_diag;                // fused sweep also stores rvor, dive, v_cc, v_ll
+    int dbg;                      // ablation switches for traffic attribution (env BEOM_DBG; 0 in production)
     // stress work arrays
     double *layt, *layb, *layu, *taub, *taum;
     // constants by value

@@ -483,10 +483,51 @@ struct UVio {
 // self, cb, ca, cd (u: W,N,NW; v: S,E,SE) — from global memory, or from the LDS tile in the
 // fused sweep.  STORE=false evaluates without any global store (halo cells) and returns the
 // new transport of this component.
-template <bool XDIR, bool PROD, bool STORE, class C>
+// Where a momentum update finds the five fields BOTH updates read (hlay, mont, pvor and the
+// viscous products pcd, qlr) at the cell, at its "b" neighbour (u: W, v: S) and at its "a"
+// neighbour (u: N, v: E): global memory, or the LDS image staged by the fused u+v sweep.
+#define UV_TX 64
+#define UV_Q 2
+#define UV_TY (4 * UV_Q)
+#define UV_LDX (UV_TX + 1 + 1)
+#define UV_SROWS (UV_TY + 2)
+#define UV_SLDX (UV_TX + 2 + 1)
+typedef double UVstage[UV_SROWS][UV_SLDX];           // rows y0-1 .. y0+TY, cols x0-1 .. x0+TX
+
+struct ShGlobal {
+    const DevView &d; int ipnt, cb, ca, ilay;
+    __device__ __forceinline__ double hlay_s() const { return LL(d.hlay, ipnt, ilay); }
+    __device__ __forceinline__ double hlay_b() const { return LL(d.hlay, cb, ilay); }
+    __device__ __forceinline__ double mont_s() const { return LL(d.mont, ipnt, ilay); }
+    __device__ __forceinline__ double mont_b() const { return LL(d.mont, cb, ilay); }
+    __device__ __forceinline__ double pvor_s() const { return LL(d.pvor, ipnt, ilay); }
+    __device__ __forceinline__ double pvor_a() const { return LL(d.pvor, ca, ilay); }
+    __device__ __forceinline__ double pcd_s() const { return LL(d.pcd, ipnt, ilay); }
+    __device__ __forceinline__ double pcd_b() const { return LL(d.pcd, cb, ilay); }
+    __device__ __forceinline__ double qlr_s() const { return LL(d.qlr, ipnt, ilay); }
+    __device__ __forceinline__ double qlr_a() const { return LL(d.qlr, ca, ilay); }
+};
+template <bool XDIR>
+struct ShLds {                                       // field order in the stage: 0 hlay 1 mont 2 pvor 3 pcd 4 qlr
+    const UVstage *s; int r, c;                      // staged position of the cell
+    static constexpr int RB = XDIR ? 0 : -1, CB = XDIR ? -1 : 0;   // b neighbour: W | S
+    static constexpr int RA = XDIR ? 1 : 0, CA = XDIR ? 0 : 1;     // a neighbour: N | E
+    __device__ __forceinline__ double hlay_s() const { return s[0][r][c]; }
+    __device__ __forceinline__ double hlay_b() const { return s[0][r + RB][c + CB]; }
+    __device__ __forceinline__ double mont_s() const { return s[1][r][c]; }
+    __device__ __forceinline__ double mont_b() const { return s[1][r + RB][c + CB]; }
+    __device__ __forceinline__ double pvor_s() const { return s[2][r][c]; }
+    __device__ __forceinline__ double pvor_a() const { return s[2][r + RA][c + CA]; }
+    __device__ __forceinline__ double pcd_s() const { return s[3][r][c]; }
+    __device__ __forceinline__ double pcd_b() const { return s[3][r + RB][c + CB]; }
+    __device__ __forceinline__ double qlr_s() const { return s[4][r][c]; }
+    __device__ __forceinline__ double qlr_a() const { return s[4][r + RA][c + CA]; }
+};
+
+template <bool XDIR, bool PROD, bool STORE, class C, class SH>
 __device__ __forceinline__ double uv_core(const C &c, const DevView &d, int ilay, double gene, double ramp,
                                           double ctim, int copy_hist, const UVio &io,
-                                          double q0, double qb, double qa, double qd) {
+                                          double q0, double qb, double qa, double qd, const SH &sh) {
     const int ipnt = c.ipnt;
     // u: cb = W(5), ca = N(3);   v: cb = S(7), ca = E(1)
     const int cb = XDIR ? c.template nb<5>() : c.template nb<7>();
@@ -497,11 +538,12 @@ __device__ __forceinline__ double uv_core(const C &c, const DevView &d, int ilay
     constexpr int IO = XDIR ? 2 : 1;               // the other one (Ekman term of ufor/vfor)
     const double i_dl = d.i_dl, i_r0 = d.i_r0, i_r1 = d.i_r1;
     const double mask = XDIR ? c.mk_u() : c.mk_v();
-    const double hcen = XDIR ? (LL(d.hlay, cb, ilay) + LL(d.hlay, ipnt, ilay)) / (1.0 + mask)
-                             : (LL(d.hlay, ipnt, ilay) + LL(d.hlay, cb, ilay)) / (1.0 + mask);
+    const double h_self = sh.hlay_s(), m_self = sh.mont_s(), pv0 = sh.pvor_s();
+    const double hcen = XDIR ? (sh.hlay_b() + h_self) / (1.0 + mask)
+                             : (h_self + sh.hlay_b()) / (1.0 + mask);
     double vold = LL(io.vel_in, ipnt, ilay);
-    const double dmd4 = (LL(d.mont, cb, ilay) - LL(d.mont, ipnt, ilay)) * i_dl * d.grav * mask;
-    const double pv0 = LL(d.pvor, ipnt, ilay), pva = LL(d.pvor, ca, ilay);
+    const double dmd4 = (sh.mont_b() - m_self) * i_dl * d.grav * mask;
+    const double pva = sh.pvor_a();
     double rhsi = dmd4 * (1.0 - gene);
     if (XDIR) rhsi = rhsi + 0.25 * pv0 * (q0 + qb) + 0.25 * pva * (qa + qd);
     else      rhsi = rhsi - 0.25 * pv0 * (q0 + qb) - 0.25 * pva * (qa + qd);
@@ -520,8 +562,8 @@ __device__ __forceinline__ double uv_core(const C &c, const DevView &d, int ilay
                        + d.epsi * LL(io.dm0, ipnt, ilay)) * gene;
     }
     if (PROD) {       // products staged by k_mont_visc: pcd = v_cc*dive, qlr = v_ll*rvor
-        const double p0 = LL(d.pcd, ipnt, ilay), pb = LL(d.pcd, cb, ilay);
-        const double l0 = LL(d.qlr, ipnt, ilay), la = LL(d.qlr, ca, ilay);
+        const double p0 = sh.pcd_s(), pb = sh.pcd_b();
+        const double l0 = sh.qlr_s(), la = sh.qlr_a();
         if (XDIR) rhsi = rhsi + (p0 - pb) * i_dl - (la - l0) * i_dl;
         else      rhsi = rhsi + (p0 - pb) * i_dl + (la - l0) * i_dl;
     } else {
@@ -578,8 +620,9 @@ __device__ __forceinline__ void body_update_uv(const C &c, const DevView &d, int
     const double *hq = XDIR ? d.h_v : d.h_u;       // the transport of the OTHER component
     double *const *dm = XDIR ? d.dmx : d.dmy;
     const UVio io{XDIR ? d.u : d.v, XDIR ? d.u : d.v, XDIR ? d.h_u : d.h_v, dm[0], dm[1], dm[2], dm[0]};
+    const ShGlobal sh{d, ipnt, cb, ca, ilay};
     uv_core<XDIR, PROD, true>(c, d, ilay, gene, ramp, ctim, copy_hist, io,
-                              LL(hq, ipnt, ilay), LL(hq, cb, ilay), LL(hq, ca, ilay), LL(hq, cd, ilay));
+                              LL(hq, ipnt, ilay), LL(hq, cb, ilay), LL(hq, ca, ilay), LL(hq, cd, ilay), sh);
 }
 template <class CTX, bool XDIR, bool PROD = false>
 __global__ __launch_bounds__(BEOM_BLOCK) void k_update_uv(DevView d, int ilay_only, double gene,
@@ -602,14 +645,10 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_update_uv(DevView d, int ilay_on
 //      buffers (pointer swap afterwards), and the SECOND update's transport is written out of
 //      place as well (the first update of other workgroups still reads the old one).
 //      Algorithmic traffic: 22 words per cell-layer instead of 14 + 14.
-#define UV_TX 64
-#define UV_Q 2
-#define UV_TY (4 * UV_Q)
-#define UV_LDX (UV_TX + 1 + 1)
-
-template <bool FIRST_X, bool PROD, bool STORE, bool INT>
+// first update at one cell; SH = where its shared fields come from
+template <bool FIRST_X, bool PROD, bool STORE, bool INT, class SH>
 __device__ __forceinline__ double uv_first_eval(const DevView &d, const CellDenseT<INT> &c, int ilay, double gene,
-                                                double ramp, double ctim) {
+                                                double ramp, double ctim, const SH &sh) {
     const int ipnt = c.ipnt;
     const int cb = FIRST_X ? c.template nb<5>() : c.template nb<7>();
     const int ca = FIRST_X ? c.template nb<3>() : c.template nb<1>();
@@ -618,33 +657,51 @@ __device__ __forceinline__ double uv_first_eval(const DevView &d, const CellDens
     double *const *dm = FIRST_X ? d.dmx : d.dmy;
     const UVio io{FIRST_X ? d.u : d.v, FIRST_X ? d.u_alt : d.v_alt, FIRST_X ? d.h_u : d.h_v,
                   dm[0], dm[1], dm[2], dm[3]};
-    return uv_core<FIRST_X, PROD, STORE>(c, d, ilay, gene, ramp, ctim, 0, io,
-                                         LL(hq, ipnt, ilay), LL(hq, cb, ilay), LL(hq, ca, ilay), LL(hq, cd, ilay));
+    return uv_core<FIRST_X, PROD, STORE>(c, d, ilay, gene, ramp, ctim, 0, io, LL(hq, ipnt, ilay),
+                                         LL(hq, cb, ilay), LL(hq, ca, ilay), LL(hq, cd, ilay), sh);
 }
 
-// new first-component transport seen by a NEIGHBOUR lookup of the local target (a, b)
-template <bool FIRST_X, bool PROD, bool INT>
+// boundary workgroups: new first-component transport seen by a NEIGHBOUR lookup of the local
+// target (a, b) — wraps / sentinel applied, everything from global memory
+template <bool FIRST_X, bool PROD>
 __device__ __forceinline__ double uv_first_halo(const DevView &d, int a, int b, int ilay, double gene,
                                                 double ramp, double ctim) {
-    if (!INT) {
-        if (d.xper) { if (a == 0) a = d.L - 1; else if (a == d.L) a = 1; }
-        if (d.yper && !d.slab) { if (b == 0) b = d.M - 1; else if (b == d.M) b = 1; }
-        if (a < 1 || a > d.L || b < 1 || b > d.M) return 0.0;      // sentinel: h_u(0) = h_v(0) = 0
-    }
-    CellDenseT<INT> h;
+    if (d.xper) { if (a == 0) a = d.L - 1; else if (a == d.L) a = 1; }
+    if (d.yper && !d.slab) { if (b == 0) b = d.M - 1; else if (b == d.M) b = 1; }
+    if (a < 1 || a > d.L || b < 1 || b > d.M) return 0.0;          // sentinel: h_u(0) = h_v(0) = 0
+    CellDenseT<false> h;
     h.set_cell(d, a, b);
-    return uv_first_eval<FIRST_X, PROD, false, INT>(d, h, ilay, gene, ramp, ctim);
+    const int cb = FIRST_X ? h.template nb<5>() : h.template nb<7>();
+    const int ca = FIRST_X ? h.template nb<3>() : h.template nb<1>();
+    const ShGlobal sh{d, h.ipnt, cb, ca, ilay};
+    return uv_first_eval<FIRST_X, PROD, false, false>(d, h, ilay, gene, ramp, ctim, sh);
 }
 
+// INT = true (tile and ring strictly inside the wet interior, the bulk of the grid) with PROD:
+// the five shared fields of tile + ring are staged in LDS once and both updates, ring cells
+// included, read them there.  Boundary workgroups (wraps, sentinel, masks) and the v_cc/v_ll
+// form read global memory as the unfused sweeps do.
 template <bool FIRST_X, bool PROD, bool INT>
 __device__ __forceinline__ void body_uv_fused(const DevView &d, int x0, int y0, int ilay, double gene,
-                                              double ramp, double ctim, double (*s_h)[UV_LDX]) {
+                                              double ramp, double ctim, double (*s_h)[UV_LDX], UVstage *s_f) {
+    constexpr bool STAGED = INT && PROD;
     const int tid = threadIdx.x;
     const int lx = tid & 63, wy = tid >> 6;
     const int i = x0 + lx;
-    // LDS coordinates: FIRST_X  -> rows y0-1 .. y0+TY-1, cols x0 .. x0+TX   (own cell at [r+1][lx])
+    // s_h coordinates: FIRST_X  -> rows y0-1 .. y0+TY-1, cols x0 .. x0+TX   (own cell at [r+1][lx])
     //                  !FIRST_X -> rows y0 .. y0+TY,     cols x0-1 .. x0+TX-1 (own cell at [r][lx+1])
     constexpr int ROFF = FIRST_X ? 1 : 0, COFF = FIRST_X ? 0 : 1;
+    if (STAGED) {
+        const double *src[5] = {d.hlay, d.mont, d.pvor, d.pcd, d.qlr};
+        const long long lay = d.n1 * (long long)(ilay - 1);
+        for (int idx = tid; idx < UV_SROWS * (UV_TX + 2); idx += BEOM_BLOCK) {
+            const int rr = idx / (UV_TX + 2), cc = idx - rr * (UV_TX + 2);
+            const long long ip = (long long)(x0 - 1 + cc) + (long long)(y0 - 2 + rr) * d.L + lay;
+#pragma unroll
+            for (int f = 0; f < 5; ++f) s_f[f][rr][cc] = src[f][ip];
+        }
+        __syncthreads();
+    }
     CellDenseT<INT> c[UV_Q];
     bool ok[UV_Q];
 #pragma unroll
@@ -654,29 +711,48 @@ __device__ __forceinline__ void body_uv_fused(const DevView &d, int x0, int y0, 
         c[q].set_cell(d, ok[q] ? i : 1, ok[q] ? j : 1);
         double hnew = 0.0;
         if (ok[q]) {
-            hnew = uv_first_eval<FIRST_X, PROD, true, INT>(d, c[q], ilay, gene, ramp, ctim);
-            if (!INT) {     // orphan column/row are wrap TARGETS: stage what a neighbour lookup returns
-                if ((d.xper && i == d.L) || (d.yper && !d.slab && j == d.M))
-                    hnew = uv_first_halo<FIRST_X, PROD, INT>(d, i, j, ilay, gene, ramp, ctim);
+            if (STAGED) {
+                const ShLds<FIRST_X> sh{s_f, r + 1, lx + 1};
+                hnew = uv_first_eval<FIRST_X, PROD, true, INT>(d, c[q], ilay, gene, ramp, ctim, sh);
+            } else {
+                const int cb = FIRST_X ? c[q].template nb<5>() : c[q].template nb<7>();
+                const int ca = FIRST_X ? c[q].template nb<3>() : c[q].template nb<1>();
+                const ShGlobal sh{d, c[q].ipnt, cb, ca, ilay};
+                hnew = uv_first_eval<FIRST_X, PROD, true, INT>(d, c[q], ilay, gene, ramp, ctim, sh);
+                if (!INT) {     // orphan column/row are wrap TARGETS: stage what a neighbour lookup returns
+                    if ((d.xper && i == d.L) || (d.yper && !d.slab && j == d.M))
+                        hnew = uv_first_halo<FIRST_X, PROD>(d, i, j, ilay, gene, ramp, ctim);
+                }
             }
         }
         s_h[r + ROFF][lx + COFF] = hnew;
     }
     // ring cells: one row (65) + one column (UV_TY)
     {
-        int a = 0, b = 0, rr = -1, cc = -1;
+        int rr = -1, cc = -1;
         if (tid <= UV_TX) {                       // the extra row
             rr = FIRST_X ? 0 : UV_TY; cc = tid;
         } else if (tid <= UV_TX + UV_TY) {        // the extra column
             rr = (tid - UV_TX - 1) + ROFF; cc = FIRST_X ? UV_TX : 0;
         }
         if (rr >= 0) {
-            a = (FIRST_X ? x0 : x0 - 1) + cc;
-            b = (FIRST_X ? y0 - 1 : y0) + rr;
-            s_h[rr][cc] = uv_first_halo<FIRST_X, PROD, INT>(d, a, b, ilay, gene, ramp, ctim);
+            const int a = (FIRST_X ? x0 : x0 - 1) + cc;
+            const int b = (FIRST_X ? y0 - 1 : y0) + rr;
+            double hv;
+            if (d.dbg & 1) hv = 0.0;
+            else if (STAGED) {
+                CellDenseT<INT> h;
+                h.set_cell(d, a, b);
+                const ShLds<FIRST_X> sh{s_f, b - (y0 - 1), a - (x0 - 1)};
+                hv = uv_first_eval<FIRST_X, PROD, false, INT>(d, h, ilay, gene, ramp, ctim, sh);
+            } else {
+                hv = uv_first_halo<FIRST_X, PROD>(d, a, b, ilay, gene, ramp, ctim);
+            }
+            s_h[rr][cc] = hv;
         }
     }
     __syncthreads();
+    if (d.dbg & 2) return;
     // second component, transport of the first from LDS
     double *const *dm = FIRST_X ? d.dmy : d.dmx;
     const UVio io{FIRST_X ? d.v : d.u, FIRST_X ? d.v : d.u, FIRST_X ? d.hv_alt : d.hu_alt,
@@ -691,13 +767,22 @@ __device__ __forceinline__ void body_uv_fused(const DevView &d, int x0, int y0, 
         } else {         // u: self, W, N, NW of h_v
             q0 = s_h[r][lx + 1]; qb = s_h[r][lx]; qa = s_h[r + 1][lx + 1]; qd = s_h[r + 1][lx];
         }
-        uv_core<!FIRST_X, PROD, true>(c[q], d, ilay, gene, ramp, ctim, 0, io, q0, qb, qa, qd);
+        if (STAGED) {
+            const ShLds<!FIRST_X> sh{s_f, r + 1, lx + 1};
+            uv_core<!FIRST_X, PROD, true>(c[q], d, ilay, gene, ramp, ctim, 0, io, q0, qb, qa, qd, sh);
+        } else {
+            const int cb = !FIRST_X ? c[q].template nb<5>() : c[q].template nb<7>();
+            const int ca = !FIRST_X ? c[q].template nb<3>() : c[q].template nb<1>();
+            const ShGlobal sh{d, c[q].ipnt, cb, ca, ilay};
+            uv_core<!FIRST_X, PROD, true>(c[q], d, ilay, gene, ramp, ctim, 0, io, q0, qb, qa, qd, sh);
+        }
     }
 }
 
 template <bool FIRST_X, bool PROD>
 __global__ __launch_bounds__(BEOM_BLOCK) void k_uv_fused(DevView d, double gene, double ramp, double ctim) {
     __shared__ double s_h[UV_TY + 1][UV_LDX];
+    __shared__ UVstage s_f[PROD ? 5 : 1];
     const int gx = (d.L + UV_TX - 1) / UV_TX;
     const int gy = (d.M + UV_TY - 1) / UV_TY;
     const int rpx = (gy + 7) / 8;
@@ -710,8 +795,8 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_uv_fused(DevView d, double gene,
     const int ilay = blockIdx.y + 1;
     const bool interior = x0 - 1 >= 2 && x0 + UV_TX <= d.L - 2 && y0 - 1 >= 2 && y0 + UV_TY <= d.M - 2
                           && y0 - 1 + d.joff >= 2 && y0 + UV_TY + d.joff <= d.Mg - 2;
-    if (interior) body_uv_fused<FIRST_X, PROD, true>(d, x0, y0, ilay, gene, ramp, ctim, s_h);
-    else body_uv_fused<FIRST_X, PROD, false>(d, x0, y0, ilay, gene, ramp, ctim, s_h);
+    if (interior) body_uv_fused<FIRST_X, PROD, true>(d, x0, y0, ilay, gene, ramp, ctim, s_h, s_f);
+    else body_uv_fused<FIRST_X, PROD, false>(d, x0, y0, ilay, gene, ramp, ctim, s_h, s_f);
 }
 static inline dim3 uv_fused_grid(const DevView &d) {
     const int gx = (d.L + UV_TX - 1) / UV_TX;
