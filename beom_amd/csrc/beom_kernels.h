@@ -349,6 +349,17 @@ __device__ __forceinline__ void body_mont_visc(const DevView &d, int x0, int y0,
             s_rv[buf][hr][hc] = a;
             s_dv[buf][hr][hc] = b;
         }
+        // The thickness loads of the second half do not depend on the staged ring: issue them
+        // BEFORE the barrier so that one memory round trip per layer serves both halves
+        // (measured: 1.64 -> 1.46 ms per launch at 4096^2 x 4).
+        double ph0[MV_Q], phE[MV_Q], phW[MV_Q], phN[MV_Q], phS[MV_Q], ph6[MV_Q];
+#pragma unroll
+        for (int q = 0; q < MV_Q; ++q) {
+            ph0[q] = LL(d.hlay, c[q].ipnt, ilay);
+            phE[q] = LL(d.hlay, n1[q], ilay); phW[q] = LL(d.hlay, n5[q], ilay);
+            phN[q] = LL(d.hlay, n3[q], ilay); phS[q] = LL(d.hlay, n7[q], ilay);
+            ph6[q] = LL(d.hlay, n6[q], ilay);
+        }
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < MV_Q; ++q) {
@@ -360,7 +371,7 @@ __device__ __forceinline__ void body_mont_visc(const DevView &d, int x0, int y0,
             const double mk1 = cc.template mk_n_nb<1>(n1[q]), mk3 = cc.template mk_n_nb<3>(n3[q]),
                          mk5 = cc.template mk_n_nb<5>(n5[q]), mk6 = cc.template mk_n_nb<6>(n6[q]),
                          mk7 = cc.template mk_n_nb<7>(n7[q]);
-            const double h0 = LL(d.hlay, ipnt, ilay);
+            const double h0 = ph0[q];
             double mpot = -0.0;
             if (d.ocrp != 0.0) {
                 mpot = h0 + d.hmin * (1.0 - mkn);
@@ -373,8 +384,7 @@ __device__ __forceinline__ void body_mont_visc(const DevView &d, int x0, int y0,
             if (d.rgld < 0.5) mpot = hcol[q] - h_th[q] + mpot;
             LL(d.mont, ipnt, ilay) = mpot + 0.25 * d.uadv * i_gr
                                           * (u_ri[q] * u_ri[q] + u_le[q] * u_le[q] + v_to[q] * v_to[q] + v_bo[q] * v_bo[q]);
-            const double hE = LL(d.hlay, n1[q], ilay), hW = LL(d.hlay, n5[q], ilay),
-                         hN = LL(d.hlay, n3[q], ilay), hS = LL(d.hlay, n7[q], ilay);
+            const double hE = phE[q], hW = phW[q], hN = phN[q], hS = phS[q];
             double d2x = (hE + hW - h0 * 2.0) * mk1 * mk5 * mkn;
             double d2y = (hN + hS - h0 * 2.0) * mk3 * mk7 * mkn;
             if (d.ocrp > 0.5) {
@@ -383,7 +393,7 @@ __device__ __forceinline__ void body_mont_visc(const DevView &d, int x0, int y0,
             }
             LL(d.d2hx, ipnt, ilay) = d2x;
             LL(d.d2hy, ipnt, ilay) = d2y;
-            const double have = h0 + hW + LL(d.hlay, n6[q], ilay) + hS;
+            const double have = h0 + hW + ph6[q] + hS;
             LL(d.pvor, ipnt, ilay) = (fcor[q] + rv[q] * d.uadv) * mkpi * (mkn + mk5 + mk6 + mk7) / have;
             // Leith viscosity from the staged ring (same names as :2458-2470)
             const double r_bl = rv[q], r_br = s_rv[buf][r][cx + 1], r_tr = s_rv[buf][r + 1][cx + 1],
