@@ -103,6 +103,9 @@ def load(path: Optional[str] = None) -> C.CDLL:
     lib.beom_sync.argtypes = [H, cp, ci]
     lib.beom_set_stream.argtypes = [H, C.c_void_p, ci]
     lib.beom_set_option.argtypes = [H, cp, ci]
+    lib.beom_step_phase.argtypes = [H, ci, cd, cd, cd, cd, ci, ci, cp, ci]
+    lib.beom_pack_rows.argtypes = [H, ci, ci, C.c_void_p]
+    lib.beom_unpack_rows.argtypes = [H, ci, ci, C.c_void_p]
     lib.beom_profile_start.argtypes = [H]
     lib.beom_profile_stop.argtypes = [H, dpp, C.POINTER(ci), cp, ci]
     lib.beom_update_h.argtypes = [H, cd, cd, cd]
@@ -121,7 +124,8 @@ def load(path: Optional[str] = None) -> C.CDLL:
                  "beom_update_h", "beom_update_mont_rvor_pvor_dive_kine", "beom_update_viscosity",
                  "beom_update_u", "beom_update_v", "beom_rebuild_fluxes", "beom_distribute_stress",
                  "beom_device_field", "beom_is_dense", "beom_profile_steps", "beom_set_stream",
-                 "beom_profile_start", "beom_profile_stop", "beom_set_option"):
+                 "beom_profile_start", "beom_profile_stop", "beom_set_option", "beom_step_phase",
+                 "beom_pack_rows", "beom_unpack_rows"):
         getattr(lib, name).restype = ci
     if lib.beom_abi_version() != BEOM_ABI_VERSION:
         raise RuntimeError("ABI mismatch")
@@ -134,7 +138,8 @@ EXPORTS = ("beom_abi_version", "beom_device_count", "beom_create", "beom_destroy
            "beom_sync", "beom_update_h", "beom_update_mont_rvor_pvor_dive_kine",
            "beom_update_viscosity", "beom_update_u", "beom_update_v", "beom_rebuild_fluxes",
            "beom_distribute_stress", "beom_device_field", "beom_is_dense", "beom_profile_steps",
-           "beom_set_stream", "beom_profile_start", "beom_profile_stop", "beom_set_option")
+           "beom_set_stream", "beom_profile_start", "beom_profile_stop", "beom_set_option",
+           "beom_step_phase", "beom_pack_rows", "beom_unpack_rows")
 
 STATE_NAMES = ("hlay", "u", "v", "h_u", "h_v", "rs_h", "dmdx", "dmdy", "v_cc", "v_ll",
                "tt3d", "tb3d", "tu3d")
@@ -218,6 +223,22 @@ class Engine:
             self._check(self.lib.beom_set_stream(self.h, None, 1))
         else:
             self._check(self.lib.beom_set_stream(self.h, C.c_void_p(hip_stream), 0))
+
+    def step_phase(self, tstp: int, phase: int, tres: float = 0.0) -> bool:
+        """Split step (beom_step_phase).  False if not available for this step."""
+        p = self.p
+        rc = self.lib.beom_step_phase(self.h, tstp, tres, float(p.dtd8), float(p.dt_r),
+                                      float(p.rsta), p.n_3d, phase, self._err, ERRLEN)
+        if rc == -20:
+            return False
+        self._check(rc)
+        return True
+
+    def pack_rows(self, jlo: int, nrows: int, tensor):
+        self._check(self.lib.beom_pack_rows(self.h, jlo, nrows, C.c_void_p(tensor.data_ptr())))
+
+    def unpack_rows(self, jlo: int, nrows: int, tensor):
+        self._check(self.lib.beom_unpack_rows(self.h, jlo, nrows, C.c_void_p(tensor.data_ptr())))
 
     def set_option(self, name: str, value: int):
         self._check(self.lib.beom_set_option(self.h, name.encode(), int(value)))

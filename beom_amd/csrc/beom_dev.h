@@ -19,6 +19,9 @@ struct DevView {
     long long n1;                 // ndeg + 1
     int L, M, xper, yper;         // dense closed form: L = lm+1, M = mm+1 (local rows)
     int joff, Mg, slab;           // j-slab: local row j is global row j + joff of Mg = mm_global+1 rows
+    // rows a launch may WRITE: up to two strips [jlo, jhi] (local, inclusive); default one strip 1..M.
+    // Used to split a step into an interior pass and an edge pass around the ghost-row exchange.
+    int nstrip, jlo[2], jhi[2];
     // static
     const int32_t *neig, *subc;
     const double *mk_u, *mk_v, *mk_n, *mkpe, *mkpi, *fcor, *h_th, *h_to;
@@ -46,6 +49,41 @@ struct DevView {
     // which optional terms are live (wave-uniform branches)
     int has_hdot, has_tide, has_bodf, has_nudg, has_stress, has_wind, has_hto;
 };
+
+// ---- tile rows of the selected strips --------------------------------------------------
+// A launch covers the tile rows (TY rows each) that intersect the strips; workgroups are dealt
+// to the 8 XCDs in bands of those tile rows (MI355X_MICROARCH.md: consecutive workgroups go
+// round-robin to the XCDs), so each XCD sweeps its own rows and its L2 keeps the neighbours.
+struct TileMap {
+    int tr0[2], ntr[2], total, rpx, gx;
+    __host__ __device__ TileMap(const DevView &d, int TX, int TY) {
+        gx = (d.L + TX - 1) / TX;
+        total = 0;
+        for (int s = 0; s < 2; ++s) {
+            tr0[s] = 0; ntr[s] = 0;
+            if (s < d.nstrip && d.jhi[s] >= d.jlo[s]) {
+                tr0[s] = (d.jlo[s] - 1) / TY;
+                ntr[s] = (d.jhi[s] - 1) / TY - tr0[s] + 1;
+            }
+            total += ntr[s];
+        }
+        rpx = (total + 7) / 8;
+    }
+    __host__ unsigned blocks() const { return (unsigned)(8 * rpx * gx); }
+    // blockIdx.x -> tile row (absolute) and column chunk; false if this workgroup has no tile
+    __device__ __forceinline__ bool locate(int b, int &ty, int &ch) const {
+        const int xcd = b & 7, k = b >> 3;
+        const int rib = k / gx;
+        ch = k - rib * gx;
+        const int vt = xcd * rpx + rib;
+        if (rib >= rpx || vt >= total) return false;
+        ty = vt < ntr[0] ? tr0[0] + vt : tr0[1] + (vt - ntr[0]);
+        return true;
+    }
+};
+__host__ __device__ __forceinline__ bool row_selected(const DevView &d, int j) {
+    return (j >= d.jlo[0] && j <= d.jhi[0]) || (d.nstrip > 1 && j >= d.jlo[1] && j <= d.jhi[1]);
+}
 
 // ---- cell contexts: where a thread is, who its neighbours are, what its masks are ----
 // Slots follow private_mod.f95:28-30: 1=E 2=NE 3=N 4=NW 5=W 6=SW 7=S 8=SE.
@@ -107,25 +145,19 @@ struct CellDenseT {
     int i, j, ipnt, L, M, xper, yper;
     int jg, Mg, ywrap;            // global row / row count (masks); y wrap only when not a slab
     static dim3 grid(const DevView &d, int nz) {
-        const int gx = (d.L + BEOM_TILE_X - 1) / BEOM_TILE_X;
-        const int gy = (d.M + BEOM_TILE_Y - 1) / BEOM_TILE_Y;
-        const int rpx = (gy + 7) / 8;
-        return dim3((unsigned)(8 * rpx * gx), (unsigned)nz, 1);
+        return dim3(TileMap(d, BEOM_TILE_X, BEOM_TILE_Y).blocks(), (unsigned)nz, 1);
     }
     __device__ __forceinline__ bool init(const DevView &d) {
         L = d.L; M = d.M; xper = d.xper; yper = d.yper;
-        const int gx = (L + BEOM_TILE_X - 1) / BEOM_TILE_X;
-        const int gy = (M + BEOM_TILE_Y - 1) / BEOM_TILE_Y;
-        const int rpx = (gy + 7) / 8;
-        const int b = blockIdx.x;
-        const int xcd = b & 7, k = b >> 3;
-        const int rib = k / gx, ch = k - rib * gx;
+        const TileMap tm(d, BEOM_TILE_X, BEOM_TILE_Y);
+        int ty, ch;
+        if (!tm.locate(blockIdx.x, ty, ch)) return false;
         const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-        j = (xcd * rpx + rib) * BEOM_TILE_Y + wave / BEOM_TILE_WX + 1;
+        j = ty * BEOM_TILE_Y + wave / BEOM_TILE_WX + 1;
         i = ch * BEOM_TILE_X + (wave % BEOM_TILE_WX) * 64 + ((int)threadIdx.x & 63) + 1;
         ipnt = i + (j - 1) * L;
         jg = j + d.joff; Mg = d.Mg; ywrap = d.yper && !d.slab;
-        return j <= M && i <= L;
+        return j <= M && i <= L && row_selected(d, j);
     }
     // context of an arbitrary LOCAL cell (a, b) of the same frame (used for halo cells)
     __device__ __forceinline__ void set_cell(const DevView &d, int a, int b) {

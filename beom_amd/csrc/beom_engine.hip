@@ -174,6 +174,7 @@ int beom_create(const beom_params *prm, int device, const int32_t *neig, const i
     for (int i = 0; i < prm->nlay; ++i) d.i_rn[i] = 1.0 / prm->rhon[i];   // :2329
     // periodicity is encoded only in neig (private_mod.f95:614-685); recover it for the dense form
     d.xper = 0; d.yper = 0;
+    d.nstrip = 1; d.jlo[0] = 1; d.jhi[0] = d.M; d.jlo[1] = 1; d.jhi[1] = 0;
     d.slab = prm->slab_mm > 0 ? 1 : 0;
     d.joff = d.slab ? prm->slab_row0 : 0;
     d.Mg = d.slab ? prm->slab_mm + 1 : d.M;
@@ -386,12 +387,12 @@ static inline void swp(double *&a, double *&b) { double *t = a; a = b; b = t; }
 static void launch_rebuild(beom_engine *E) {
     LAUNCH_CTX(k_rebuild_fluxes<CellGather>, k_rebuild_fluxes<CellDense>, E->d.nlay, E->d);
 }
-static void launch_h(beom_engine *E, double gene, double ramp, double ctim) {
+static void launch_h(beom_engine *E, double gene, double ramp, double ctim, bool rotate = true) {
     // variant 1 couples layers inside a cell -> one thread walks nlay..1; variant 0: layer = blockIdx.y
     const int nz = (E->d.variant == 1) ? 1 : E->d.nlay;
     if (E->d.has_nudg) LAUNCH_CTX((k_update_h<CellGather, true>), (k_update_h<CellDense, true>), nz, E->d, gene, ramp, ctim, 0);
     else LAUNCH_CTX((k_update_h<CellGather, false>), (k_update_h<CellDense, false>), nz, E->d, gene, ramp, ctim, 0);
-    rot2(E->d.rs);
+    if (rotate) rot2(E->d.rs);
 }
 template <class CTX>
 static bool launch_mont_all(beom_engine *E) {
@@ -433,18 +434,24 @@ static bool launch_mont_visc(beom_engine *E) {
     }
 }
 // fused U+V sweep (dense frames): first_x = update_u first (even tstp)
-static void launch_uv_fused(beom_engine *E, bool first_x, bool prod, double gene, double ramp, double ctim) {
+static void uv_fused_swap(beom_engine *E, bool first_x) {
+    DevView &d = E->d;
+    swp(d.u, d.u_alt); swp(d.v, d.v_alt);                 // both velocities are written out of place
+    if (first_x) { rot4(d.dmx); swp(d.h_v, d.hv_alt); rot3(d.dmy); }
+    else         { rot4(d.dmy); swp(d.h_u, d.hu_alt); rot3(d.dmx); }
+}
+static void launch_uv_fused(beom_engine *E, bool first_x, bool prod, double gene, double ramp, double ctim,
+                            bool swap = true) {
     const dim3 g = uv_fused_grid(E->d), b(BEOM_BLOCK);
     DevView &d = E->d;
     if (first_x) {
         if (prod) hipLaunchKernelGGL((k_uv_fused<true, true>), g, b, 0, E->stream, d, gene, ramp, ctim);
         else hipLaunchKernelGGL((k_uv_fused<true, false>), g, b, 0, E->stream, d, gene, ramp, ctim);
-        swp(d.u, d.u_alt); rot4(d.dmx); swp(d.h_v, d.hv_alt); rot3(d.dmy);
     } else {
         if (prod) hipLaunchKernelGGL((k_uv_fused<false, true>), g, b, 0, E->stream, d, gene, ramp, ctim);
         else hipLaunchKernelGGL((k_uv_fused<false, false>), g, b, 0, E->stream, d, gene, ramp, ctim);
-        swp(d.v, d.v_alt); rot4(d.dmy); swp(d.h_u, d.hu_alt); rot3(d.dmx);
     }
+    if (swap) uv_fused_swap(E, first_x);
 }
 static bool can_fuse(const beom_engine *E, int n_3d) {
     // every step must refresh the viscosity (else v_cc/v_ll have to persist): dvis > 1e-3 and n_3d = 1 (:2268)
@@ -591,6 +598,82 @@ int beom_profile_steps(beom_handle E, int tstp_first, int nsteps, double tres, d
     rc = beom_step(E, tstp_first, nsteps, tres, dtd8, dt_r, rsta, n_3d, errm, errm_len);
     if (rc) return rc;
     return beom_profile_stop(E, ms, launches, errm, errm_len);
+}
+
+// ---- split step for the ghost-row exchange overlap ------------------------
+// phase 1: every sweep on the rows whose results cannot depend on ghost rows refreshed by the
+//          exchange still in flight (the dependency front advances <= 1 row per sweep);
+// phase 2: the remaining rows next to the ghost zones, then the pointer rotations.
+// G = 4 ghost rows per neighbour (beom_amd/slab.py).  Only for the fused dense path on steps
+// > 3 without a stress update; returns -20 when the caller must use beom_step instead.
+static void set_rows(DevView &d, int n, int lo0, int hi0, int lo1 = 1, int hi1 = 0) {
+    d.nstrip = n; d.jlo[0] = lo0; d.jhi[0] = hi0; d.jlo[1] = lo1; d.jhi[1] = hi1;
+}
+
+int beom_step_phase(beom_handle E, int tstp, double tres, double dtd8, double dt_r, double rsta, int n_3d,
+                    int phase, char *errm, int errm_len) {
+    if (!E) { set_err(errm, errm_len, "null handle"); return -1; }
+    HIP_TRY(hipSetDevice(E->device));
+    DevView &d = E->d;
+    const StepScalars s = step_scalars(E, tstp, tres, dtd8, dt_r, rsta, n_3d);
+    const bool south = d.slab && d.joff > 0, north = d.slab && d.joff + d.M < d.Mg;
+    if (!(s.fused && s.fused_uv) || s.first3 || (s.stress && (E->wind || E->bot || E->top)) ||
+        !(south || north) || d.M < 32 || (phase != 1 && phase != 2)) {
+        set_err(errm, errm_len, "beom_step_phase: split step not available for this step/configuration");
+        return -20;
+    }
+    const int M = d.M;
+    const bool u_first = tstp % 2 == 0;
+    StepTimer *T = E->timer;
+    if (T) T->st = E->stream;
+    if (phase == 1) {
+        set_rows(d, 1, south ? 9 : 1, north ? M - 8 : M);
+        if (T) T->begin(0);
+        launch_h(E, s.gene, s.ramp, s.ctim, false);
+        if (T) { T->end(); T->begin(5); }
+        set_rows(d, 1, south ? 10 : 1, north ? M - 9 : M);
+        launch_mont_visc(E);
+        if (T) { T->end(); T->begin(6); }
+        set_rows(d, 1, south ? 11 : 1, north ? M - 10 : M);
+        launch_uv_fused(E, u_first, true, s.gene, s.ramp, s.ctim, false);
+        if (T) T->end();
+    } else {
+        // edge strips; a side without a neighbour has no strip (its rows were done in phase 1)
+        auto strips = [&](int depth) {
+            if (south && north) set_rows(d, 2, 1, depth, M - depth + 1, M);
+            else if (south) set_rows(d, 1, 1, depth);
+            else set_rows(d, 1, M - depth + 1, M);
+        };
+        strips(8);
+        if (T) T->begin(0);
+        launch_h(E, s.gene, s.ramp, s.ctim, true);
+        if (T) { T->end(); T->begin(5); }
+        strips(9);
+        launch_mont_visc(E);
+        if (T) { T->end(); T->begin(6); }
+        strips(10);
+        launch_uv_fused(E, u_first, true, s.gene, s.ramp, s.ctim, true);
+        if (T) T->end();
+    }
+    set_rows(d, 1, 1, M);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// rows [jlo, jlo+nrows) of hlay,u,v,h_u,h_v  ->  dbuf (device memory, 5*nlay*nrows*(lm+1) doubles)
+int beom_pack_rows(beom_handle E, int jlo, int nrows, void *dbuf) {
+    if (!E || !dbuf || jlo < 1 || nrows < 1 || jlo + nrows - 1 > E->d.M) return -3;
+    const long long total = 5ll * E->d.nlay * nrows * E->d.L;
+    hipLaunchKernelGGL((k_rows_copy<true>), dim3((unsigned)((total + BEOM_BLOCK - 1) / BEOM_BLOCK)), dim3(BEOM_BLOCK),
+                       0, E->stream, E->d, jlo, nrows, (double *)dbuf);
+    return 0;
+}
+int beom_unpack_rows(beom_handle E, int jlo, int nrows, const void *dbuf) {
+    if (!E || !dbuf || jlo < 1 || nrows < 1 || jlo + nrows - 1 > E->d.M) return -3;
+    const long long total = 5ll * E->d.nlay * nrows * E->d.L;
+    hipLaunchKernelGGL((k_rows_copy<false>), dim3((unsigned)((total + BEOM_BLOCK - 1) / BEOM_BLOCK)), dim3(BEOM_BLOCK),
+                       0, E->stream, E->d, jlo, nrows, (double *)dbuf);
+    return 0;
 }
 
 int beom_set_option(beom_handle E, const char *name, int value) {

@@ -299,13 +299,14 @@ __device__ __forceinline__ void body_mont_visc(const DevView &d, int x0, int y0,
     const double i_gr = d.i_gr, i_ns = d.i_ns, hs_8 = d.hsal;
     // own cells: rows y0+wy (+4 per extra cell)
     CellDenseT<INT> c[MV_Q];
-    bool ok[MV_Q];
+    bool ok[MV_Q], wr[MV_Q];
     double hcol[MV_Q], fcor[MV_Q], h_th[MV_Q], h_to[MV_Q];
     int n1[MV_Q], n3[MV_Q], n5[MV_Q], n6[MV_Q], n7[MV_Q];
 #pragma unroll
     for (int q = 0; q < MV_Q; ++q) {
         const int j = y0 + wy + 4 * q;
         ok[q] = (i <= d.L) && (j <= d.M);
+        wr[q] = ok[q] && row_selected(d, j);           // cells outside the strips are staged, not stored
         c[q].set_cell(d, ok[q] ? i : 1, ok[q] ? j : 1);
         n1[q] = c[q].template nb<1>(); n3[q] = c[q].template nb<3>(); n5[q] = c[q].template nb<5>();
         n6[q] = c[q].template nb<6>(); n7[q] = c[q].template nb<7>();
@@ -363,7 +364,7 @@ __device__ __forceinline__ void body_mont_visc(const DevView &d, int x0, int y0,
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < MV_Q; ++q) {
-            if (!ok[q]) continue;
+            if (!wr[q]) continue;
             const CellDenseT<INT> &cc = c[q];
             const int ipnt = cc.ipnt;
             const int r = 1 + wy + 4 * q, cx = 1 + lx;
@@ -424,15 +425,9 @@ template <int NL>
 __global__ __launch_bounds__(BEOM_BLOCK) void k_mont_visc(DevView d) {
     __shared__ double s_rv[2][MV_LDY][MV_LDX];
     __shared__ double s_dv[2][MV_LDY][MV_LDX];
-    // XCD-aware tile order: XCD x sweeps its own band of tile rows
-    const int gx = (d.L + MV_TX - 1) / MV_TX;
-    const int gy = (d.M + MV_TY - 1) / MV_TY;
-    const int rpx = (gy + 7) / 8;
-    const int b = blockIdx.x;
-    const int xcd = b & 7, k = b >> 3;
-    const int rib = k / gx, ch = k - rib * gx;
-    const int ty = xcd * rpx + rib;
-    if (ty >= gy) return;                                   // whole block: no barrier is skipped by part of it
+    const TileMap tm(d, MV_TX, MV_TY);
+    int ty, ch;
+    if (!tm.locate(blockIdx.x, ty, ch)) return;               // whole block: no barrier is skipped by part of it
     const int x0 = ch * MV_TX + 1, y0 = ty * MV_TY + 1;
     // block-uniform: tile and its ring lie in 2..L-2 x 2..M-2 (global rows too) -> no wraps, masks = 1
     const bool interior = x0 - 1 >= 2 && x0 + MV_TX <= d.L - 2 && y0 - 1 >= 2 && y0 + MV_TY <= d.M - 2
@@ -440,12 +435,7 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_mont_visc(DevView d) {
     if (interior) body_mont_visc<NL, true>(d, x0, y0, s_rv, s_dv);
     else body_mont_visc<NL, false>(d, x0, y0, s_rv, s_dv);
 }
-static inline dim3 mont_visc_grid(const DevView &d) {
-    const int gx = (d.L + MV_TX - 1) / MV_TX;
-    const int gy = (d.M + MV_TY - 1) / MV_TY;
-    const int rpx = (gy + 7) / 8;
-    return dim3((unsigned)(8 * rpx * gx), 1, 1);
-}
+static inline dim3 mont_visc_grid(const DevView &d) { return dim3(TileMap(d, MV_TX, MV_TY).blocks(), 1, 1); }
 
 // ---- update_viscosity (Leith part), private_mod.f95:2441-2502 -----------------------
 template <class C>
@@ -537,7 +527,8 @@ struct ShLds {                                       // field order in the stage
 template <bool XDIR, bool PROD, bool STORE, class C, class SH>
 __device__ __forceinline__ double uv_core(const C &c, const DevView &d, int ilay, double gene, double ramp,
                                           double ctim, int copy_hist, const UVio &io,
-                                          double q0, double qb, double qa, double qd, const SH &sh) {
+                                          double q0, double qb, double qa, double qd, const SH &sh,
+                                          bool do_store = true) {
     const int ipnt = c.ipnt;
     // u: cb = W(5), ca = N(3);   v: cb = S(7), ca = E(1)
     const int cb = XDIR ? c.template nb<5>() : c.template nb<7>();
@@ -604,7 +595,7 @@ __device__ __forceinline__ double uv_core(const C &c, const DevView &d, int ilay
     }
     const double hnew = 0.5 * (vold + fabs(vold)) * (hcen - 0.16667 * LL(d2h, cb, ilay))
                       + 0.5 * (vold - fabs(vold)) * (hcen - 0.16667 * LL(d2h, ipnt, ilay));   // rgld = 0 (:1491,1577)
-    if (STORE) {
+    if (STORE && do_store) {
         LL(io.vel_out, ipnt, ilay) = vold;
         LL(io.hp_out, ipnt, ilay) = hnew;
         if (copy_hist) {                       // single-layer entry points: shift like the reference
@@ -658,7 +649,7 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_update_uv(DevView d, int ilay_on
 // first update at one cell; SH = where its shared fields come from
 template <bool FIRST_X, bool PROD, bool STORE, bool INT, class SH>
 __device__ __forceinline__ double uv_first_eval(const DevView &d, const CellDenseT<INT> &c, int ilay, double gene,
-                                                double ramp, double ctim, const SH &sh) {
+                                                double ramp, double ctim, const SH &sh, bool do_store = true) {
     const int ipnt = c.ipnt;
     const int cb = FIRST_X ? c.template nb<5>() : c.template nb<7>();
     const int ca = FIRST_X ? c.template nb<3>() : c.template nb<1>();
@@ -668,7 +659,7 @@ __device__ __forceinline__ double uv_first_eval(const DevView &d, const CellDens
     const UVio io{FIRST_X ? d.u : d.v, FIRST_X ? d.u_alt : d.v_alt, FIRST_X ? d.h_u : d.h_v,
                   dm[0], dm[1], dm[2], dm[3]};
     return uv_core<FIRST_X, PROD, STORE>(c, d, ilay, gene, ramp, ctim, 0, io, LL(hq, ipnt, ilay),
-                                         LL(hq, cb, ilay), LL(hq, ca, ilay), LL(hq, cd, ilay), sh);
+                                         LL(hq, cb, ilay), LL(hq, ca, ilay), LL(hq, cd, ilay), sh, do_store);
 }
 
 // boundary workgroups: new first-component transport seen by a NEIGHBOUR lookup of the local
@@ -713,22 +704,23 @@ __device__ __forceinline__ void body_uv_fused(const DevView &d, int x0, int y0, 
         __syncthreads();
     }
     CellDenseT<INT> c[UV_Q];
-    bool ok[UV_Q];
+    bool ok[UV_Q], wr[UV_Q];
 #pragma unroll
     for (int q = 0; q < UV_Q; ++q) {
         const int r = wy + 4 * q, j = y0 + r;
         ok[q] = (i <= d.L) && (j <= d.M);
+        wr[q] = ok[q] && row_selected(d, j);       // cells outside the strips are evaluated, not stored
         c[q].set_cell(d, ok[q] ? i : 1, ok[q] ? j : 1);
         double hnew = 0.0;
         if (ok[q]) {
             if (STAGED) {
                 const ShLds<FIRST_X> sh{s_f, r + 1, lx + 1};
-                hnew = uv_first_eval<FIRST_X, PROD, true, INT>(d, c[q], ilay, gene, ramp, ctim, sh);
+                hnew = uv_first_eval<FIRST_X, PROD, true, INT>(d, c[q], ilay, gene, ramp, ctim, sh, wr[q]);
             } else {
                 const int cb = FIRST_X ? c[q].template nb<5>() : c[q].template nb<7>();
                 const int ca = FIRST_X ? c[q].template nb<3>() : c[q].template nb<1>();
                 const ShGlobal sh{d, c[q].ipnt, cb, ca, ilay};
-                hnew = uv_first_eval<FIRST_X, PROD, true, INT>(d, c[q], ilay, gene, ramp, ctim, sh);
+                hnew = uv_first_eval<FIRST_X, PROD, true, INT>(d, c[q], ilay, gene, ramp, ctim, sh, wr[q]);
                 if (!INT) {     // orphan column/row are wrap TARGETS: stage what a neighbour lookup returns
                     if ((d.xper && i == d.L) || (d.yper && !d.slab && j == d.M))
                         hnew = uv_first_halo<FIRST_X, PROD>(d, i, j, ilay, gene, ramp, ctim);
@@ -765,11 +757,13 @@ __device__ __forceinline__ void body_uv_fused(const DevView &d, int x0, int y0, 
     if (d.dbg & 2) return;
     // second component, transport of the first from LDS
     double *const *dm = FIRST_X ? d.dmy : d.dmx;
-    const UVio io{FIRST_X ? d.v : d.u, FIRST_X ? d.v : d.u, FIRST_X ? d.hv_alt : d.hu_alt,
+    // the second component's velocity also goes to its partner buffer: an edge pass launched
+    // after this one must still find the OLD u and v of every row (rvor/dive of its ring)
+    const UVio io{FIRST_X ? d.v : d.u, FIRST_X ? d.v_alt : d.u_alt, FIRST_X ? d.hv_alt : d.hu_alt,
                   dm[0], dm[1], dm[2], dm[0]};
 #pragma unroll
     for (int q = 0; q < UV_Q; ++q) {
-        if (!ok[q]) continue;
+        if (!wr[q]) continue;
         const int r = wy + 4 * q;
         double q0, qb, qa, qd;
         if (FIRST_X) {   // v: self, S, E, SE of h_u
@@ -793,14 +787,9 @@ template <bool FIRST_X, bool PROD>
 __global__ __launch_bounds__(BEOM_BLOCK) void k_uv_fused(DevView d, double gene, double ramp, double ctim) {
     __shared__ double s_h[UV_TY + 1][UV_LDX];
     __shared__ UVstage s_f[PROD ? 5 : 1];
-    const int gx = (d.L + UV_TX - 1) / UV_TX;
-    const int gy = (d.M + UV_TY - 1) / UV_TY;
-    const int rpx = (gy + 7) / 8;
-    const int b = blockIdx.x;
-    const int xcd = b & 7, k = b >> 3;
-    const int rib = k / gx, ch = k - rib * gx;
-    const int ty = xcd * rpx + rib;
-    if (ty >= gy) return;
+    const TileMap tm(d, UV_TX, UV_TY);
+    int ty, ch;
+    if (!tm.locate(blockIdx.x, ty, ch)) return;
     const int x0 = ch * UV_TX + 1, y0 = ty * UV_TY + 1;
     const int ilay = blockIdx.y + 1;
     const bool interior = x0 - 1 >= 2 && x0 + UV_TX <= d.L - 2 && y0 - 1 >= 2 && y0 + UV_TY <= d.M - 2
@@ -809,10 +798,7 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_uv_fused(DevView d, double gene,
     else body_uv_fused<FIRST_X, PROD, false>(d, x0, y0, ilay, gene, ramp, ctim, s_h, s_f);
 }
 static inline dim3 uv_fused_grid(const DevView &d) {
-    const int gx = (d.L + UV_TX - 1) / UV_TX;
-    const int gy = (d.M + UV_TY - 1) / UV_TY;
-    const int rpx = (gy + 7) / 8;
-    return dim3((unsigned)(8 * rpx * gx), (unsigned)d.nlay, 1);
+    return dim3(TileMap(d, UV_TX, UV_TY).blocks(), (unsigned)d.nlay, 1);
 }
 
 // ---- distribute_stress, private_mod.f95:1921-2149 -----------------------------------
@@ -900,4 +886,22 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_stress_apply(DevView d, int wind
         T3_(d.tt3d, ipnt, 1, ilay) = d.taus[ipnt] * LL(d.layt, ipnt, ilay);
         T3_(d.tt3d, ipnt, 2, ilay) = d.taus[ipnt + d.n1] * LL(d.layt, ipnt, ilay);
     }
+}
+
+// ---- ghost-row exchange support: rows [jlo, jlo+nrows) of hlay,u,v,h_u,h_v <-> one buffer ----
+// buffer layout: [field 0..4][layer][row][column], contiguous
+template <bool PACK>
+__global__ __launch_bounds__(BEOM_BLOCK) void k_rows_copy(DevView d, int jlo, int nrows, double *buf) {
+    const long long per_lay = (long long)nrows * d.L;
+    const long long total = 5ll * d.nlay * per_lay;
+    const long long t = (long long)blockIdx.x * BEOM_BLOCK + threadIdx.x;
+    if (t >= total) return;
+    const int f = (int)(t / (d.nlay * per_lay));
+    const long long r = t - (long long)f * d.nlay * per_lay;
+    const int lay = (int)(r / per_lay);
+    const long long c = r - (long long)lay * per_lay;
+    double *fld = f == 0 ? d.hlay : f == 1 ? d.u : f == 2 ? d.v : f == 3 ? d.h_u : d.h_v;
+    const long long ip = 1 + (long long)(jlo - 1) * d.L + c + d.n1 * (long long)lay;
+    if (PACK) buf[t] = fld[ip];
+    else fld[ip] = buf[t];
 }

@@ -126,10 +126,15 @@ class SlabRunner:
 
     `engine` needs: step(tstp_first, nsteps, sync=False), field_tensors() -> {name:
     tensor[nlay, n_local+1]} (views of the live state), sync(); optional profile_start/
-    profile_stop.  beom_amd.capi.Engine provides them on a GPU; tests plug in a CPU
-    adapter over the oracle to exercise exactly this exchange logic under gloo."""
+    profile_stop, pack_rows/unpack_rows (one-launch packing) and step_phase (split step).
+    beom_amd.capi.Engine provides them on a GPU; tests plug in a CPU adapter over the oracle
+    to exercise exactly this decomposition / exchange logic under gloo.
 
-    def __init__(self, engine, geom: SlabGeom, nlay: int, dist=None, device=None):
+    Overlap (GPU, `overlap=True`): the exchange of step n runs on a second HIP stream while
+    the main stream already computes the interior rows of step n+1 (beom_step_phase 1); the
+    rows next to the ghost zones follow once the ghosts have landed (phase 2)."""
+
+    def __init__(self, engine, geom: SlabGeom, nlay: int, dist=None, overlap: bool = False):
         import torch
         self.torch = torch
         self.engine = engine
@@ -144,20 +149,27 @@ class SlabRunner:
         self.has_n = geom.rank < geom.world - 1
         self.send_s, self.recv_s = (mk(), mk()) if self.has_s else (None, None)
         self.send_n, self.recv_n = (mk(), mk()) if self.has_n else (None, None)
-        # packed ranges: what I send = my outermost OWNED rows; what I receive = my ghost rows
+        # local row numbers (1-based): what I send = my outermost OWNED rows; what I receive = ghosts
+        loc = lambda g0: g0 - geom.win0 + 1
         if self.has_s:
-            self.r_send_s = geom.local_rows(geom.own0, geom.own0 + G - 1)
-            self.r_recv_s = geom.local_rows(geom.win0, geom.own0 - 1)
+            self.j_send_s, self.j_recv_s = loc(geom.own0), loc(geom.win0)
         if self.has_n:
-            self.r_send_n = geom.local_rows(geom.own1 - G + 1, geom.own1)
-            self.r_recv_n = geom.local_rows(geom.own1 + 1, geom.win1)
+            self.j_send_n, self.j_recv_n = loc(geom.own1 - G + 1), loc(geom.own1 + 1)
+        self.fast_pack = hasattr(engine, "pack_rows")
+        self.overlap = bool(overlap) and hasattr(engine, "step_phase") and ref.is_cuda and geom.world > 1
+        self._pending = None
+        if self.overlap:
+            self.main = torch.cuda.Stream(device=ref.device)
+            self.comm = torch.cuda.Stream(device=ref.device)
+            self.main.wait_stream(torch.cuda.current_stream(ref.device))
+            engine.set_stream(self.main.cuda_stream)
 
     # -- construction helpers ---------------------------------------------------------
     @classmethod
     def from_global_case(cls, p: Params, files: Dict[str, np.ndarray], rank: int, world: int,
-                         device: int = 0, variant: int = 0):
+                         device: int = 0, variant: int = 0, overlap: bool = True):
         """GPU path used by bench.py: build the global state on the host, keep this rank's
-        window, create the HIP engine on `device` and run it on torch's current stream."""
+        window, create the HIP engine on `device` and run it on a torch stream."""
         import torch
         import torch.distributed as dist
         from . import capi
@@ -168,56 +180,58 @@ class SlabRunner:
         del f
         eng = capi.Engine(lf, device=device, variant=variant, slab_row0=geom.row0, slab_mm=p.mm)
         eng.set_stream(torch.cuda.current_stream(device).cuda_stream)
-        return cls(eng, geom, p.nlay, dist=dist)
+        return cls(eng, geom, p.nlay, dist=dist, overlap=overlap)
 
     def describe(self) -> dict:
         g = self.g
         return {"ghost_rows": GHOST, "exchanges_per_step": 1, "fields": list(EXCHANGED),
                 "rows_owned": g.own1 - g.own0 + 1, "rows_local": g.rows,
                 "bytes_per_direction_per_step": len(EXCHANGED) * self.nlay * GHOST * g.L * 8,
-                "backend": "torch.distributed P2P (RCCL)"}
+                "backend": "torch.distributed P2P (RCCL)", "overlap_with_interior": self.overlap}
 
-    # -- exchange -----------------------------------------------------------------------
+    # -- packing ------------------------------------------------------------------------
     @property
     def t(self):
         # the engine may ping-pong its buffers between steps: always ask for the live views
         return self.engine.field_tensors(EXCHANGED)
 
-    def _pack(self, buf, rng):
-        a, b = rng
-        k = 0
-        t = self.t
-        m = (b - a) * self.nlay
+    def _rows(self, j):
+        return 1 + (j - 1) * self.g.L, 1 + (j - 1 + GHOST) * self.g.L
+
+    def _pack(self, buf, j):
+        if self.fast_pack:
+            self.engine.pack_rows(j, GHOST, buf)
+            return
+        a, b = self._rows(j)
+        t, k, m = self.t, 0, (b - a) * self.nlay
         for name in EXCHANGED:
             buf[k:k + m].view(self.nlay, b - a).copy_(t[name][:, a:b])
             k += m
 
-    def _unpack(self, buf, rng):
-        a, b = rng
-        k = 0
-        t = self.t
-        m = (b - a) * self.nlay
+    def _unpack(self, buf, j):
+        if self.fast_pack:
+            self.engine.unpack_rows(j, GHOST, buf)
+            return
+        a, b = self._rows(j)
+        t, k, m = self.t, 0, (b - a) * self.nlay
         for name in EXCHANGED:
             t[name][:, a:b].copy_(buf[k:k + m].view(self.nlay, b - a))
             k += m
 
     def pack_all(self):
         if self.has_s:
-            self._pack(self.send_s, self.r_send_s)
+            self._pack(self.send_s, self.j_send_s)
         if self.has_n:
-            self._pack(self.send_n, self.r_send_n)
+            self._pack(self.send_n, self.j_send_n)
 
     def unpack_all(self):
         if self.has_s:
-            self._unpack(self.recv_s, self.r_recv_s)
+            self._unpack(self.recv_s, self.j_recv_s)
         if self.has_n:
-            self._unpack(self.recv_n, self.r_recv_n)
+            self._unpack(self.recv_n, self.j_recv_n)
 
-    def exchange(self):
-        if self.g.world == 1:
-            return
+    def _p2p(self):
         dist = self.dist
-        self.pack_all()
         ops = []
         # same order of peers on both sides of a link: lower neighbour first
         if self.has_s:
@@ -228,20 +242,69 @@ class SlabRunner:
             ops.append(dist.P2POp(dist.irecv, self.recv_n, self.g.rank + 1))
         for w in dist.batch_isend_irecv(ops):
             w.wait()
+
+    def exchange(self):
+        """Blocking form (in stream order): pack, send/recv, unpack."""
+        if self.g.world == 1:
+            return
+        self.pack_all()
+        self._p2p()
         self.unpack_all()
+
+    # -- overlapped form ------------------------------------------------------------------
+    def _exchange_begin(self):
+        """After a step: pack on the main stream, then send/recv + unpack on the comm stream."""
+        torch = self.torch
+        self.pack_all()
+        packed = torch.cuda.Event()
+        packed.record(self.main)
+        with torch.cuda.stream(self.comm):
+            self.comm.wait_event(packed)
+            self._p2p()
+            self.engine.set_stream(self.comm.cuda_stream)
+            self.unpack_all()
+            self.engine.set_stream(self.main.cuda_stream)
+            done = torch.cuda.Event()
+            done.record(self.comm)
+        self._pending = done
+
+    def _exchange_end(self):
+        if self._pending is not None:
+            self.main.wait_event(self._pending)
+            self._pending = None
 
     # -- stepping -----------------------------------------------------------------------
     def step(self, tstp_first: int, nsteps: int):
-        for t in range(tstp_first, tstp_first + nsteps):
-            self.engine.step(t, 1, sync=False)
-            self.exchange()
+        if not self.overlap:
+            for t in range(tstp_first, tstp_first + nsteps):
+                self.engine.step(t, 1, sync=False)
+                self.exchange()
+            return
+        torch = self.torch
+        with torch.cuda.stream(self.main):
+            for t in range(tstp_first, tstp_first + nsteps):
+                if self._pending is not None and self.engine.step_phase(t, 1):
+                    self._exchange_end()                 # ghosts of the previous step have landed
+                    self.engine.step_phase(t, 2)
+                else:
+                    self._exchange_end()
+                    self.engine.step(t, 1, sync=False)
+                self._exchange_begin()
+
+    def finish(self):
+        """Drain the exchange in flight (before reading ghost rows or leaving the timed region)."""
+        if self.overlap:
+            self._exchange_end()
+            self.main.synchronize()
 
     def profile_steps(self, tstp_first: int, nsteps: int):
         self.engine.profile_start()
         self.step(tstp_first, nsteps)
+        self.finish()
         return self.engine.profile_stop()
 
     def sync(self):
+        self.finish()
         self.engine.sync()
 
     def owned(self, arr: np.ndarray) -> np.ndarray:

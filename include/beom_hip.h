@@ -129,6 +129,20 @@ int beom_step(beom_handle h, int tstp_first, int nsteps,
 
 int beom_sync(beom_handle h, char *errm, int errm_len);
 
+/* Multi-GPU j-slabs (no reference counterpart — the reference is OpenMP only).
+ * One time step in two parts so that the ghost-row exchange of the previous step overlaps
+ * the bulk of this one: phase 1 = every sweep on the rows that cannot depend on ghost rows
+ * still in flight, phase 2 = the rows next to the ghost zones + pointer rotations (call it
+ * once the ghosts have been refreshed).  -20 = not available for this step (steps 1-3,
+ * stress update, unfused path): use beom_step. */
+int beom_step_phase(beom_handle h, int tstp, double tres, double dtd8, double dt_r, double rsta,
+                    int n_3d, int phase, char *errm, int errm_len);
+/* Rows [jlo, jlo+nrows) (local, 1-based) of hlay,u,v,h_u,h_v <-> one contiguous DEVICE buffer
+ * of 5*nlay*nrows*(lm+1) doubles ([field][layer][row][column]); one launch each, on the
+ * handle's stream. */
+int beom_pack_rows(beom_handle h, int jlo, int nrows, void *device_buffer);
+int beom_unpack_rows(beom_handle h, int jlo, int nrows, const void *device_buffer);
+
 /* Options (dense frames only; results are bit-identical either way):
  *  "fuse_mont_visc" (default 1): with the Leith viscosity refreshed every step (dvis > 1e-3,
  *      n_3d = 1) update_mont... and update_viscosity run as ONE sweep that hands update_u/v

@@ -281,3 +281,59 @@ def test_profile_start_stop_counts_launches():
     ms, nl = e.profile_stop()
     assert nl == [4, 4, 4, 4, 4, 0, 0] and all(m > 0 for m in ms[:5])
     e.close()
+
+
+@pytest.mark.parametrize("case,world", [("closed_tall", 2), ("closed_tall", 3), ("sill_tall", 2)])
+def test_split_step_with_late_ghosts_matches_single_domain(case, world):
+    """beom_step_phase: phase 1 (interior rows) runs BEFORE the ghost rows of the previous step
+    are refreshed, phase 2 (rows next to the ghost zones) after — the order the overlapped
+    exchange produces.  Owned rows must still equal the single-domain run bit for bit."""
+    import torch
+    from beom_amd import inputs as I, slab
+    from beom_amd.grid import read_input_data
+    if case == "closed_tall":
+        p, files = I.case_headline(150, 131, 3)
+    else:
+        p, files = I.case_sill_exchange3d(lm=133, mm=141, nlay=2, dt_s=0.01, npts=5, sill_halfwidth=6.0)
+    f = read_input_data(p, files=files)
+    whole = capi.Engine(f)
+    runs = []
+    for g in slab.decompose(p.mm, p.lm, world):
+        e = capi.Engine(slab.slice_fields(f, g), slab_row0=g.row0, slab_mm=p.mm)
+        e.set_stream(torch.cuda.current_stream().cuda_stream)
+        runs.append(slab.SlabRunner(e, g, p.nlay, dist=None))
+
+    def move():
+        for k in range(world - 1):
+            runs[k + 1].recv_s.copy_(runs[k].send_n)
+            runs[k].recv_n.copy_(runs[k + 1].send_s)
+
+    nsteps, split = 14, 0
+    for t in range(1, nsteps + 1):
+        if t == 1 or not all(r.engine.step_phase(t, 1) for r in runs):
+            if t > 1:
+                move()
+                for r in runs: r.unpack_all()
+            for r in runs: r.engine.step(t, 1, sync=False)
+        else:
+            split += 1
+            move()                                   # ghosts arrive only now
+            for r in runs: r.unpack_all()
+            for r in runs: assert r.engine.step_phase(t, 2)
+        for r in runs: r.pack_all()
+    assert split >= nsteps - 3                       # steps 1-3 are never split
+    torch.cuda.synchronize()
+    whole.step(1, nsteps)
+    ref = whole.download()
+    for r in runs:
+        g = r.g
+        a, b = 1 + (g.own0 - 1) * g.L, 1 + g.own1 * g.L
+        la, lb = g.local_rows(g.own0, g.own1)
+        st = r.engine.download()
+        for k in PROGNOSTIC:
+            if k in ("rs_h", "dmdx", "dmdy"):
+                assert same(st[k][:, la:lb, :], ref[k][:, a:b, :]), (case, g.rank, k)
+            else:
+                assert same(st[k][..., la:lb], ref[k][..., a:b]), (case, g.rank, k)
+        r.engine.close()
+    whole.close()
