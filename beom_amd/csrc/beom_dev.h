@@ -21,7 +21,7 @@ struct DevView {
     int joff, Mg, slab;           // j-slab: local row j is global row j + joff of Mg = mm_global+1 rows
     // rows a launch may WRITE: up to two strips [jlo, jhi] (local, inclusive); default one strip 1..M.
     // Used to split a step into an interior pass and an edge pass around the ghost-row exchange.
-    int nstrip, jlo[2], jhi[2];
+    int nstrip, jlo0, jhi0, jlo1, jhi1;   // (scalars, never indexed: indexing a kernel argument sends it to scratch)
     // static
     const int32_t *neig, *subc;
     const double *mk_u, *mk_v, *mk_n, *mkpe, *mkpi, *fcor, *h_th, *h_to;
@@ -55,18 +55,15 @@ struct DevView {
 // to the 8 XCDs in bands of those tile rows (MI355X_MICROARCH.md: consecutive workgroups go
 // round-robin to the XCDs), so each XCD sweeps its own rows and its L2 keeps the neighbours.
 struct TileMap {
-    int tr0[2], ntr[2], total, rpx, gx;
-    __host__ __device__ TileMap(const DevView &d, int TX, int TY) {
+    int tr0a, ntra, tr0b, ntrb, total, rpx, gx;
+    // forceinline: an out-of-line call would take the address of the kernel argument and push all
+    // of DevView (~1 KB per lane) into scratch memory
+    __host__ __device__ __forceinline__ TileMap(const DevView &d, int TX, int TY) {
         gx = (d.L + TX - 1) / TX;
-        total = 0;
-        for (int s = 0; s < 2; ++s) {
-            tr0[s] = 0; ntr[s] = 0;
-            if (s < d.nstrip && d.jhi[s] >= d.jlo[s]) {
-                tr0[s] = (d.jlo[s] - 1) / TY;
-                ntr[s] = (d.jhi[s] - 1) / TY - tr0[s] + 1;
-            }
-            total += ntr[s];
-        }
+        tr0a = 0; ntra = 0; tr0b = 0; ntrb = 0;
+        if (d.jhi0 >= d.jlo0) { tr0a = (d.jlo0 - 1) / TY; ntra = (d.jhi0 - 1) / TY - tr0a + 1; }
+        if (d.nstrip > 1 && d.jhi1 >= d.jlo1) { tr0b = (d.jlo1 - 1) / TY; ntrb = (d.jhi1 - 1) / TY - tr0b + 1; }
+        total = ntra + ntrb;
         rpx = (total + 7) / 8;
     }
     __host__ unsigned blocks() const { return (unsigned)(8 * rpx * gx); }
@@ -77,12 +74,12 @@ struct TileMap {
         ch = k - rib * gx;
         const int vt = xcd * rpx + rib;
         if (rib >= rpx || vt >= total) return false;
-        ty = vt < ntr[0] ? tr0[0] + vt : tr0[1] + (vt - ntr[0]);
+        ty = vt < ntra ? tr0a + vt : tr0b + (vt - ntra);
         return true;
     }
 };
 __host__ __device__ __forceinline__ bool row_selected(const DevView &d, int j) {
-    return (j >= d.jlo[0] && j <= d.jhi[0]) || (d.nstrip > 1 && j >= d.jlo[1] && j <= d.jhi[1]);
+    return (j >= d.jlo0 && j <= d.jhi0) || (d.nstrip > 1 && j >= d.jlo1 && j <= d.jhi1);
 }
 
 // ---- cell contexts: where a thread is, who its neighbours are, what its masks are ----

@@ -174,7 +174,7 @@ int beom_create(const beom_params *prm, int device, const int32_t *neig, const i
     for (int i = 0; i < prm->nlay; ++i) d.i_rn[i] = 1.0 / prm->rhon[i];   // :2329
     // periodicity is encoded only in neig (private_mod.f95:614-685); recover it for the dense form
     d.xper = 0; d.yper = 0;
-    d.nstrip = 1; d.jlo[0] = 1; d.jhi[0] = d.M; d.jlo[1] = 1; d.jhi[1] = 0;
+    d.nstrip = 1; d.jlo0 = 1; d.jhi0 = d.M; d.jlo1 = 1; d.jhi1 = 0;
     d.slab = prm->slab_mm > 0 ? 1 : 0;
     d.joff = d.slab ? prm->slab_row0 : 0;
     d.Mg = d.slab ? prm->slab_mm + 1 : d.M;
@@ -607,7 +607,7 @@ int beom_profile_steps(beom_handle E, int tstp_first, int nsteps, double tres, d
 // G = 4 ghost rows per neighbour (beom_amd/slab.py).  Only for the fused dense path on steps
 // > 3 without a stress update; returns -20 when the caller must use beom_step instead.
 static void set_rows(DevView &d, int n, int lo0, int hi0, int lo1 = 1, int hi1 = 0) {
-    d.nstrip = n; d.jlo[0] = lo0; d.jhi[0] = hi0; d.jlo[1] = lo1; d.jhi[1] = hi1;
+    d.nstrip = n; d.jlo0 = lo0; d.jhi0 = hi0; d.jlo1 = lo1; d.jhi1 = hi1;
 }
 
 int beom_step_phase(beom_handle E, int tstp, double tres, double dtd8, double dt_r, double rsta, int n_3d,

@@ -325,8 +325,9 @@ __device__ __forceinline__ void body_mont_visc(const DevView &d, int x0, int y0,
     if (hr >= 0) { ha = x0 - 1 + hc; hb = y0 - 1 + hr; }
 
     // the few re-reads of the cell's own column hit L1/L2
-#pragma unroll MV_UNROLL
-    for (int l = 0; l < NL; ++l) {
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {      // must stay unrolled: d.rhon[l] may not become a dynamic index
+
         const int ilay = l + 1, buf = l & 1;
         double rv[MV_Q], dv[MV_Q], u_le[MV_Q], u_ri[MV_Q], v_bo[MV_Q], v_to[MV_Q];
 #pragma unroll
@@ -381,6 +382,7 @@ __device__ __forceinline__ void body_mont_visc(const DevView &d, int x0, int y0,
             }
             mpot = mpot - h_to[q];
             const double i_rn = d.i_rn[l];
+#pragma unroll
             for (int m = 0; m < l; ++m) mpot = mpot - (d.rhon[l] - d.rhon[m]) * i_rn * LL(d.hlay, ipnt, m + 1);
             if (d.rgld < 0.5) mpot = hcol[q] - h_th[q] + mpot;
             LL(d.mont, ipnt, ilay) = mpot + 0.25 * d.uadv * i_gr
