@@ -99,10 +99,32 @@ def main():
         exchange_desc = None
     else:
         from beom_amd import slab
-        runner = slab.SlabRunner.from_global_case(p, files, rank, world, device=local_rank)
+        runner = slab.SlabRunner.from_global_case(p, files, rank, world, device=local_rank,
+                                                  overlap=os.environ.get("BEOM_NO_OVERLAP") is None)
         del files
         dense = runner.engine.is_dense
+        # self-check on THIS machine: the overlapped exchange must give the owned rows of the plain
+        # (step, exchange, step, ...) form bit for bit; if not, time the plain form
+        verified = None
+        if runner.overlap:
+            def owned_copy():
+                a, b = runner.g.local_rows(runner.g.own0, runner.g.own1)
+                return [t[:, a:b].clone() for t in runner.engine.field_tensors().values()]
+            runner.overlap = False
+            runner.step(1, 9); runner.sync()
+            ref_rows = owned_copy()
+            runner.reset_state()
+            runner.overlap = True
+            runner.step(1, 9); runner.sync()
+            same = all(torch.equal(x, y) for x, y in zip(ref_rows, owned_copy()))
+            flag = torch.tensor([1 if same else 0], device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            verified = bool(flag.item())
+            runner.overlap = verified
+            runner.reset_state()
+            del ref_rows
         exchange_desc = runner.describe()
+        exchange_desc["overlap_verified_bitwise_vs_plain_exchange"] = verified
     t_setup = time.time() - t0
 
     def barrier():
@@ -129,7 +151,8 @@ def main():
     units_per_step = float(p.ndeg) * p.nlay              # cell-layer updates in one step, whole job
     value = units_per_step * K / elapsed
     # dominant kernel = the longest-running sweep of this run
-    per_launch_ms = [ms[i] / nl[i] if nl[i] else 0.0 for i in range(NCLS)]
+    # a split step launches each sweep twice (interior + edge rows): account per STEP
+    per_launch_ms = [ms[i] / K if nl[i] else 0.0 for i in range(NCLS)]
     dom = max(range(NCLS), key=lambda i: ms[i])
     units_per_launch = units_per_step / world            # one launch covers this rank's slab, all layers
     ach = B_ALG_KERNEL[KERNEL_ORDER[dom]] * units_per_launch / (per_launch_ms[dom] * 1e-3) / 1e9

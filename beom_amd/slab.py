@@ -156,9 +156,13 @@ class SlabRunner:
         if self.has_n:
             self.j_send_n, self.j_recv_n = loc(geom.own1 - G + 1), loc(geom.own1 + 1)
         self.fast_pack = hasattr(engine, "pack_rows")
-        self.overlap = bool(overlap) and hasattr(engine, "step_phase") and ref.is_cuda and geom.world > 1
+        self.can_overlap = hasattr(engine, "step_phase") and ref.is_cuda and geom.world > 1
+        self.overlap = bool(overlap) and self.can_overlap
         self._pending = None
-        if self.overlap:
+        self.main = self.comm = None
+        if ref.is_cuda and hasattr(engine, "set_stream"):
+            # the engine, the packing and the exchange share ONE explicit stream (`main`); the
+            # overlapped form adds `comm` for the transfer + unpack
             self.main = torch.cuda.Stream(device=ref.device)
             self.comm = torch.cuda.Stream(device=ref.device)
             self.main.wait_stream(torch.cuda.current_stream(ref.device))
@@ -179,8 +183,17 @@ class SlabRunner:
         lf = slice_fields(f, geom)
         del f
         eng = capi.Engine(lf, device=device, variant=variant, slab_row0=geom.row0, slab_mm=p.mm)
-        eng.set_stream(torch.cuda.current_stream(device).cuda_stream)
-        return cls(eng, geom, p.nlay, dist=dist, overlap=overlap)
+        run = cls(eng, geom, p.nlay, dist=dist, overlap=overlap)
+        run.local_fields = lf
+        return run
+
+    def reset_state(self):
+        """Back to the initial state of this slab (bench: verification and timed runs start equal)."""
+        from .capi import STATE_NAMES
+        self.finish()
+        self.engine.sync()
+        self.engine.upload(**{k: getattr(self.local_fields, k) for k in STATE_NAMES})
+        self._pending = None
 
     def describe(self) -> dict:
         g = self.g
@@ -231,7 +244,14 @@ class SlabRunner:
             self._unpack(self.recv_n, self.j_recv_n)
 
     def _p2p(self):
-        dist = self.dist
+        dist, torch = self.dist, self.torch
+        buf = self.recv_s if self.has_s else self.recv_n
+        # RCCL orders the transfer after the CURRENT stream's work and wait() orders the current
+        # stream after the transfer.  gloo (one-GPU rehearsals) stages CUDA tensors through the
+        # host outside any stream order: fence the device on both sides of it.
+        fence = buf.is_cuda and dist.get_backend() != "nccl"
+        if fence:
+            torch.cuda.synchronize()
         ops = []
         # same order of peers on both sides of a link: lower neighbour first
         if self.has_s:
@@ -242,6 +262,8 @@ class SlabRunner:
             ops.append(dist.P2POp(dist.irecv, self.recv_n, self.g.rank + 1))
         for w in dist.batch_isend_irecv(ops):
             w.wait()
+        if fence:
+            torch.cuda.synchronize()
 
     def exchange(self):
         """Blocking form (in stream order): pack, send/recv, unpack."""
@@ -252,21 +274,28 @@ class SlabRunner:
         self.unpack_all()
 
     # -- overlapped form ------------------------------------------------------------------
-    def _exchange_begin(self):
-        """After a step: pack on the main stream, then send/recv + unpack on the comm stream."""
-        torch = self.torch
+    def _begin_pack(self):
+        """After a step: pack the outermost owned rows on the main stream."""
         self.pack_all()
-        packed = torch.cuda.Event()
-        packed.record(self.main)
+        self._packed = self.torch.cuda.Event()
+        self._packed.record(self.main)
+
+    def _begin_transfer(self, transfer=None):
+        """Send/recv + unpack on the comm stream; `transfer` replaces the P2P (tests)."""
+        torch = self.torch
         with torch.cuda.stream(self.comm):
-            self.comm.wait_event(packed)
-            self._p2p()
+            self.comm.wait_event(self._packed)
+            (transfer or self._p2p)()
             self.engine.set_stream(self.comm.cuda_stream)
             self.unpack_all()
             self.engine.set_stream(self.main.cuda_stream)
             done = torch.cuda.Event()
             done.record(self.comm)
         self._pending = done
+
+    def _exchange_begin(self):
+        self._begin_pack()
+        self._begin_transfer()
 
     def _exchange_end(self):
         if self._pending is not None:
@@ -275,12 +304,15 @@ class SlabRunner:
 
     # -- stepping -----------------------------------------------------------------------
     def step(self, tstp_first: int, nsteps: int):
-        if not self.overlap:
-            for t in range(tstp_first, tstp_first + nsteps):
-                self.engine.step(t, 1, sync=False)
-                self.exchange()
-            return
         torch = self.torch
+        if not self.overlap:
+            import contextlib
+            ctx = torch.cuda.stream(self.main) if self.main is not None else contextlib.nullcontext()
+            with ctx:
+                for t in range(tstp_first, tstp_first + nsteps):
+                    self.engine.step(t, 1, sync=False)
+                    self.exchange()
+            return
         with torch.cuda.stream(self.main):
             for t in range(tstp_first, tstp_first + nsteps):
                 if self._pending is not None and self.engine.step_phase(t, 1):
@@ -293,7 +325,7 @@ class SlabRunner:
 
     def finish(self):
         """Drain the exchange in flight (before reading ghost rows or leaving the timed region)."""
-        if self.overlap:
+        if self.main is not None:
             self._exchange_end()
             self.main.synchronize()
 

@@ -337,3 +337,63 @@ def test_split_step_with_late_ghosts_matches_single_domain(case, world):
                 assert same(st[k][..., la:lb], ref[k][..., a:b]), (case, g.rank, k)
         r.engine.close()
     whole.close()
+
+
+def test_overlapped_streams_two_slabs_one_process():
+    """The overlapped SlabRunner protocol with REAL stream concurrency on one GPU: each slab has
+    its main and comm stream; the transfer is an asynchronous device copy on the comm stream, so
+    phase 1 of step n+1 runs while the ghosts of step n are still being copied and unpacked."""
+    import torch
+    from beom_amd import inputs as I, slab
+    from beom_amd.grid import read_input_data
+    p, files = I.case_headline(300, 259, 4)
+    f = read_input_data(p, files=files)
+    whole = capi.Engine(f)
+    geoms = slab.decompose(p.mm, p.lm, 2)
+    runs = []
+    for g in geoms:
+        e = capi.Engine(slab.slice_fields(f, g), slab_row0=g.row0, slab_mm=p.mm)
+        r = slab.SlabRunner(e, g, p.nlay, dist=None, overlap=False)
+        # switch the overlap machinery on by hand (no process group in this test)
+        r.overlap = True
+        r.main, r.comm = torch.cuda.Stream(), torch.cuda.Stream()
+        r.main.wait_stream(torch.cuda.current_stream())
+        e.set_stream(r.main.cuda_stream)
+        runs.append(r)
+    a, b = runs
+
+    def xfer(dst, src_runner, src):
+        def go():
+            torch.cuda.current_stream().wait_event(src_runner._packed)
+            dst.copy_(src, non_blocking=True)
+        return go
+
+    nsteps, split = 40, 0
+    for t in range(1, nsteps + 1):
+        for r in runs:
+            with torch.cuda.stream(r.main):
+                if r._pending is not None and r.engine.step_phase(t, 1):
+                    split += 1
+                    r._exchange_end()
+                    assert r.engine.step_phase(t, 2)
+                else:
+                    r._exchange_end()
+                    r.engine.step(t, 1, sync=False)
+        for r in runs:
+            r._begin_pack()
+        a._begin_transfer(xfer(a.recv_n, b, b.send_s))
+        b._begin_transfer(xfer(b.recv_s, a, a.send_n))
+    for r in runs:
+        r.finish()
+    assert split == 2 * (nsteps - 3)
+    whole.step(1, nsteps)
+    ref = whole.download()
+    for r in runs:
+        g = r.g
+        ga, gb = 1 + (g.own0 - 1) * g.L, 1 + g.own1 * g.L
+        la, lb = g.local_rows(g.own0, g.own1)
+        st = r.engine.download()
+        for k in ("hlay", "u", "v", "h_u", "h_v"):
+            assert same(st[k][:, la:lb], ref[k][:, ga:gb]), (g.rank, k)
+        r.engine.close()
+    whole.close()
