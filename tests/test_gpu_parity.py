@@ -229,8 +229,8 @@ def test_slabs_on_one_gpu_match_single_domain(case, world):
         lf = slab.slice_fields(f, g)
         e = capi.Engine(lf, slab_row0=g.row0, slab_mm=p.mm)
         assert e.is_dense
-        e.set_stream(torch.cuda.current_stream().cuda_stream)
         runs.append(slab.SlabRunner(e, g, p.nlay, dist=None))
+        e.set_stream(torch.cuda.current_stream().cuda_stream)     # this test drives everything on ONE stream
     # the tensors are views of the live device state, not copies
     t0 = runs[0].t["hlay"]
     keep = t0[0, 5].item()
@@ -300,8 +300,8 @@ def test_split_step_with_late_ghosts_matches_single_domain(case, world):
     runs = []
     for g in slab.decompose(p.mm, p.lm, world):
         e = capi.Engine(slab.slice_fields(f, g), slab_row0=g.row0, slab_mm=p.mm)
-        e.set_stream(torch.cuda.current_stream().cuda_stream)
         runs.append(slab.SlabRunner(e, g, p.nlay, dist=None))
+        e.set_stream(torch.cuda.current_stream().cuda_stream)     # one stream: ordering by program order
 
     def move():
         for k in range(world - 1):
