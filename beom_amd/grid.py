@@ -228,15 +228,17 @@ def equilibrium_h0_ocrp(p: Params, g, h_2d) -> np.ndarray:
         cons[il] = dmax * (-1.0) + _seq_sum(gues0, 0)
         for k in range(il):
             cons[il] = cons[il] - (rho8[il] - rho8[k]) * gues0[k] / rho8[il]
-    cells = np.flatnonzero(g["mk_n"] > 0.5)
-    hbot = g["h_th"][cells].astype(f8)
+    cells_all = np.flatnonzero(g["mk_n"] > 0.5)
+    # the column solve depends on the cell only through its depth: solve once per distinct depth
+    hbot, inverse = np.unique(g["h_th"][cells_all].astype(f8), return_inverse=True)
+    cells = np.arange(hbot.size)                  # columns of the reduced problem
     n = cells.size
     gues = np.zeros((nlay, n))
     for il in range(nlay - 1, -1, -1):                             # :370-380
         habv = dmax * topl[il]
         hbel = _seq_sum(gues[il + 1:], 0) if il < nlay - 1 else 0.0
         gues[il] = np.maximum(hbot - habv - hbel, hsal)
-    h_0 = np.zeros((nlay, ndeg + 1), dtype=f8)
+    h_u = np.zeros((nlay, n), dtype=f8)           # solution per distinct depth
     active = np.arange(n)
     for it in range(1, p.itmx + 1):
         G = gues[:, active]
@@ -253,7 +255,7 @@ def equilibrium_h0_ocrp(p: Params, g, h_2d) -> np.ndarray:
             raise RuntimeError("calculation of h_layers did not converge")
         conv = np.all(np.abs(func) < thre, axis=0)                 # :403-408
         if conv.any():
-            h_0[:, cells[active[conv]]] = G[:, conv]
+            h_u[:, cells[active[conv]]] = G[:, conv]
         keep = ~conv
         if not keep.any():
             break
@@ -297,6 +299,8 @@ def equilibrium_h0_ocrp(p: Params, g, h_2d) -> np.ndarray:
         if low.any():
             G[:, low] = np.maximum(G[:, low], thre)
         gues[:, active] = G
+    h_0 = np.zeros((nlay, ndeg + 1), dtype=f8)
+    h_0[:, cells_all] = h_u[:, inverse]
     return h_0
 
 
