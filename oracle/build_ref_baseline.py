@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, HERE)
 
 SAMPLE = (1024, 1024, 4)
-NSTEPS = 150
+NSTEPS = 1200        # ~15-25 s of reference CPU work on a 16-core share
 
 
 def params(lm, mm, nlay, nsteps=NSTEPS):
