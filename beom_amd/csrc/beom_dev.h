@@ -93,6 +93,7 @@ template <int K> struct NbOff {
 
 // Any coastline: neighbours and masks come from the caller's tables.
 struct CellGather {
+    static constexpr bool kLanesAreRowNeighbours = false;
     int ipnt;
     const int32_t *row;
     const DevView *dv;
@@ -139,6 +140,9 @@ struct CellGather {
 
 template <bool INTERIOR>
 struct CellDenseT {
+    // lane l and lane l+1 of an INTERIOR wave hold cells (i, j) and (i+1, j): an east/west
+    // neighbour value is one wavefront shuffle away instead of one more load
+    static constexpr bool kLanesAreRowNeighbours = INTERIOR;
     int i, j, ipnt, L, M, xper, yper;
     int jg, Mg, ywrap;            // global row / row count (masks); y wrap only when not a slab
     static dim3 grid(const DevView &d, int nz) {

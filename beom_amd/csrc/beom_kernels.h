@@ -60,7 +60,15 @@ __device__ __forceinline__ void body_update_h(const C &c, const DevView &d, doub
     const int ilay_lo = gridDim.y == 1 ? 1 : (int)blockIdx.y + 1;
     for (int ilay = ilay_hi; ilay >= ilay_lo; --ilay) {
         double hold = LL(d.hlay, ipnt, ilay);
-        double rs_3 = (LL(d.h_u, ipnt, ilay) - LL(d.h_u, c1, ilay)) * i_dl
+        const double hu0 = LL(d.h_u, ipnt, ilay);
+        double huE;
+        if (C::kLanesAreRowNeighbours) {        // flux divergence in x: east value by wavefront shuffle
+            huE = __shfl_down(hu0, 1, 64);
+            if ((threadIdx.x & 63) == 63) huE = LL(d.h_u, c1, ilay);
+        } else {
+            huE = LL(d.h_u, c1, ilay);
+        }
+        double rs_3 = (hu0 - huE) * i_dl
                     + (LL(d.h_v, ipnt, ilay) - LL(d.h_v, c3, ilay)) * i_dl
                     + (d.has_hdot ? LL(d.hdot, ipnt, ilay) : 0.0);
         rs_3 = rs_3 * mkn;
