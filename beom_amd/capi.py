@@ -103,6 +103,7 @@ def load(path: Optional[str] = None) -> C.CDLL:
     lib.beom_sync.argtypes = [H, cp, ci]
     lib.beom_set_stream.argtypes = [H, C.c_void_p, ci]
     lib.beom_set_option.argtypes = [H, cp, ci]
+    lib.beom_download_outputs.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, dpp, C.POINTER(ci), cp, ci]
     lib.beom_step_phase.argtypes = [H, ci, cd, cd, cd, cd, ci, ci, cp, ci]
     lib.beom_pack_rows.argtypes = [H, ci, ci, C.c_void_p]
     lib.beom_unpack_rows.argtypes = [H, ci, ci, C.c_void_p]
@@ -125,7 +126,7 @@ def load(path: Optional[str] = None) -> C.CDLL:
                  "beom_update_u", "beom_update_v", "beom_rebuild_fluxes", "beom_distribute_stress",
                  "beom_device_field", "beom_is_dense", "beom_profile_steps", "beom_set_stream",
                  "beom_profile_start", "beom_profile_stop", "beom_set_option", "beom_step_phase",
-                 "beom_pack_rows", "beom_unpack_rows"):
+                 "beom_pack_rows", "beom_unpack_rows", "beom_download_outputs"):
         getattr(lib, name).restype = ci
     if lib.beom_abi_version() != BEOM_ABI_VERSION:
         raise RuntimeError("ABI mismatch")
@@ -139,7 +140,7 @@ EXPORTS = ("beom_abi_version", "beom_device_count", "beom_create", "beom_destroy
            "beom_update_viscosity", "beom_update_u", "beom_update_v", "beom_rebuild_fluxes",
            "beom_distribute_stress", "beom_device_field", "beom_is_dense", "beom_profile_steps",
            "beom_set_stream", "beom_profile_start", "beom_profile_stop", "beom_set_option",
-           "beom_step_phase", "beom_pack_rows", "beom_unpack_rows")
+           "beom_step_phase", "beom_pack_rows", "beom_unpack_rows", "beom_download_outputs")
 
 STATE_NAMES = ("hlay", "u", "v", "h_u", "h_v", "rs_h", "dmdx", "dmdy", "v_cc", "v_ll",
                "tt3d", "tb3d", "tu3d")
@@ -239,6 +240,18 @@ class Engine:
 
     def unpack_rows(self, jlo: int, nrows: int, tensor):
         self._check(self.lib.beom_unpack_rows(self.h, jlo, nrows, C.c_void_p(tensor.data_ptr())))
+
+    def download_outputs(self, h0r4: Optional[np.ndarray]):
+        """(eta, u, v) real*4 records [nlay, ndeg], minmax [nlay, 6], thin_layer — formed on the device."""
+        n = (self.p.nlay, self.p.ndeg)
+        eta, u4, v4 = (np.zeros(n, dtype=np.float32) for _ in range(3))
+        mm = np.zeros((self.p.nlay, 6))
+        thin = C.c_int(0)
+        hp = h0r4.ctypes.data_as(C.c_void_p) if h0r4 is not None else None
+        self._check(self.lib.beom_download_outputs(self.h, hp, eta.ctypes.data_as(C.c_void_p),
+                                                   u4.ctypes.data_as(C.c_void_p), v4.ctypes.data_as(C.c_void_p),
+                                                   _dp(mm), C.byref(thin), self._err, ERRLEN))
+        return eta, u4, v4, mm, thin.value
 
     def set_option(self, name: str, value: int):
         self._check(self.lib.beom_set_option(self.h, name.encode(), int(value)))

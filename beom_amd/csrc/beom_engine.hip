@@ -48,6 +48,9 @@ struct beom_engine {
     // geometry of the launches
     dim3 grid_cells0, grid_cells_layers_flat;
     bool wind = false, bot = false, top = false;
+    float *h0r4_dev = nullptr, *out4[3] = {nullptr, nullptr, nullptr};   // device-side output staging
+    double *scan_dev = nullptr;
+    int any_u = 0, any_v = 0;
     bool fuse = true;                  // dense frames: Montgomery+Leith in one sweep (k_mont_visc)
     bool fuse_uv = true;               // dense frames: update_u + update_v in one sweep (k_uv_fused)
     char last_err[512] = {0};
@@ -197,6 +200,7 @@ int beom_create(const beom_params *prm, int device, const int32_t *neig, const i
     UP(nudg, nudg, 3 * n1) UP(fnud, fnud, 3 * nl * n1) UP(hdot, hdot, nl * n1)
     UP(tide, tide, 6 * n1) UP(bodf, bodf, 2 * nl) UP(taus, taus, 2 * n1)
 #undef UP
+    for (size_t i = 0; i < n1; ++i) { if (mk_u[i] > 0.5) E->any_u = 1; if (mk_v[i] > 0.5) E->any_v = 1; }
     d.has_hdot = any_nonzero(hdot, nl * n1);
     d.has_tide = any_nonzero(tide, 6 * n1);
     d.has_bodf = any_nonzero(bodf, 2 * nl);
@@ -673,6 +677,56 @@ int beom_unpack_rows(beom_handle E, int jlo, int nrows, const void *dbuf) {
     const long long total = 5ll * E->d.nlay * nrows * E->d.L;
     hipLaunchKernelGGL((k_rows_copy<false>), dim3((unsigned)((total + BEOM_BLOCK - 1) / BEOM_BLOCK)), dim3(BEOM_BLOCK),
                        0, E->stream, E->d, jlo, nrows, (double *)dbuf);
+    return 0;
+}
+
+// Output preparation on the device: replaces the array work of write_array for
+// 'eta_', 'u___', 'v___' (private_mod.f95:2848-2883) and the min/max + thin-layer scans of
+// write_outputs (:2772-2808).  Only real*4 records cross PCIe.
+int beom_download_outputs(beom_handle E, const float *h0r4, float *eta, float *u4, float *v4,
+                          double *minmax, int *thin_layer, char *errm, int errm_len) {
+    if (!E) { set_err(errm, errm_len, "null handle"); return -1; }
+    HIP_TRY(hipSetDevice(E->device));
+    DevView &d = E->d;
+    const size_t n = (size_t)d.ndeg * d.nlay;
+    if (!E->h0r4_dev) {
+        if (!h0r4) { set_err(errm, errm_len, "beom_download_outputs: h_0 (real*4) needed on the first call"); return -3; }
+        HIP_TRY(hipMalloc((void **)&E->h0r4_dev, n * sizeof(float)));
+        E->allocs.push_back(E->h0r4_dev);
+        for (int q = 0; q < 3; ++q) { HIP_TRY(hipMalloc((void **)&E->out4[q], n * sizeof(float))); E->allocs.push_back(E->out4[q]); }
+        const size_t nb = (size_t)E->grid_cells0.x;
+        HIP_TRY(hipMalloc((void **)&E->scan_dev, nb * d.nlay * 7 * sizeof(double)));
+        E->allocs.push_back(E->scan_dev);
+    }
+    if (h0r4) HIP_TRY(hipMemcpyAsync(E->h0r4_dev, h0r4, n * sizeof(float), hipMemcpyHostToDevice, E->stream));
+    const unsigned gx = (unsigned)((d.ndeg + BEOM_BLOCK - 1) / BEOM_BLOCK);
+    if (eta || u4 || v4) {
+        hipLaunchKernelGGL(k_out_convert, dim3(gx), dim3(BEOM_BLOCK), 0, E->stream, d, E->h0r4_dev,
+                           eta ? E->out4[0] : nullptr, u4 ? E->out4[1] : nullptr, v4 ? E->out4[2] : nullptr);
+        float *host[3] = {eta, u4, v4};
+        for (int q = 0; q < 3; ++q)
+            if (host[q]) HIP_TRY(hipMemcpyAsync(host[q], E->out4[q], n * sizeof(float), hipMemcpyDeviceToHost, E->stream));
+    }
+    if (minmax || thin_layer) {
+        const size_t nb = (size_t)E->grid_cells0.x;
+        hipLaunchKernelGGL(k_out_scan, E->grid_cells0, dim3(BEOM_BLOCK), 0, E->stream, d, E->any_u, E->any_v, E->scan_dev);
+        std::vector<double> part(nb * d.nlay * 7);
+        HIP_TRY(hipMemcpyAsync(part.data(), E->scan_dev, part.size() * sizeof(double), hipMemcpyDeviceToHost, E->stream));
+        HIP_TRY(hipStreamSynchronize(E->stream));
+        if (thin_layer) *thin_layer = 0;
+        for (int k = 0; k < d.nlay; ++k) {
+            double r[7] = {1.7976931348623157e308, -1.7976931348623157e308, 1.7976931348623157e308,
+                           -1.7976931348623157e308, 1.7976931348623157e308, -1.7976931348623157e308, 0.0};
+            for (size_t b = 0; b < nb; ++b) {
+                const double *p = &part[(b * d.nlay + k) * 7];
+                for (int q = 0; q < 7; ++q) r[q] = (q == 0 || q == 2 || q == 4) ? std::fmin(r[q], p[q]) : std::fmax(r[q], p[q]);
+            }
+            if (minmax) for (int q = 0; q < 6; ++q) minmax[k * 6 + q] = r[q];
+            if (thin_layer && r[6] > 0.5 && *thin_layer == 0) *thin_layer = k + 1;
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(E->stream));
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 

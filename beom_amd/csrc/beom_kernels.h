@@ -915,3 +915,60 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_rows_copy(DevView d, int jlo, in
     if (PACK) buf[t] = fld[ip];
     else fld[ip] = buf[t];
 }
+
+// ---- device-side output preparation: write_array 'eta_','u___','v___'
+//      (:2848-2883) and the scans of write_outputs (:2772-2808) ---------------------------
+// eta: interface elevation accumulated bottom-up in real*4 exactly as the reference does
+// (each partial sum is rounded to real*4 before the next layer is added, :2855-2858).
+__global__ __launch_bounds__(BEOM_BLOCK) void k_out_convert(DevView d, const float *h0r4, float *eta, float *u4,
+                                                            float *v4) {
+    const int ipnt = blockIdx.x * BEOM_BLOCK + threadIdx.x + 1;
+    if (ipnt > d.ndeg) return;
+    const long long nd = d.ndeg;
+    float acc = 0.f;
+    for (int k = d.nlay; k >= 1; --k) {
+        const long long o = (long long)(ipnt - 1) + nd * (k - 1);
+        const double h = LL(d.hlay, ipnt, k) - (double)h0r4[o];
+        acc = (k == d.nlay) ? (float)h : (float)(h + (double)acc);
+        if (eta) eta[o] = acc;
+        if (u4) u4[o] = (float)LL(d.u, ipnt, k);
+        if (v4) v4[o] = (float)LL(d.v, ipnt, k);
+    }
+}
+
+// per-workgroup partial min/max of h (wet cells), u, v (their points, or all cells 0..ndeg when a
+// mask is empty, :2776-2793) and the thin-layer flag (:2799-2800); the host reduces the partials.
+// out: [block][layer][7] = hmin,hmax,umin,umax,vmin,vmax,thin
+__global__ __launch_bounds__(BEOM_BLOCK) void k_out_scan(DevView d, int any_u, int any_v, double *out) {
+    __shared__ double red[BEOM_BLOCK / 64][7];
+    const int ipnt = blockIdx.x * BEOM_BLOCK + threadIdx.x;          // 0..ndeg
+    const bool in = ipnt <= d.ndeg;
+    const double big = 1.7976931348623157e308;
+    for (int k = 1; k <= d.nlay; ++k) {
+        double v[7] = {big, -big, big, -big, big, -big, 0.0};
+        if (in) {
+            const double h = LL(d.hlay, ipnt, k), uu = LL(d.u, ipnt, k), vv = LL(d.v, ipnt, k);
+            if (d.mk_n[ipnt] > 0.5) { v[0] = h; v[1] = h; if (ipnt >= 1 && h < 0.5 * d.hmin) v[6] = 1.0; }
+            if (!any_u || d.mk_u[ipnt] > 0.5) { v[2] = uu; v[3] = uu; }
+            if (!any_v || d.mk_v[ipnt] > 0.5) { v[4] = vv; v[5] = vv; }
+        }
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+            double x = v[q];
+            for (int off = 32; off > 0; off >>= 1) {
+                const double y = __shfl_down(x, off, 64);
+                x = (q == 0 || q == 2 || q == 4) ? fmin(x, y) : fmax(x, y);
+            }
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][q] = x;
+        }
+        __syncthreads();
+        if (threadIdx.x < 7) {
+            const int q = threadIdx.x;
+            double x = red[0][q];
+            for (int w = 1; w < BEOM_BLOCK / 64; ++w)
+                x = (q == 0 || q == 2 || q == 4) ? fmin(x, red[w][q]) : fmax(x, red[w][q]);
+            out[((long long)blockIdx.x * d.nlay + (k - 1)) * 7 + q] = x;
+        }
+        __syncthreads();
+    }
+}

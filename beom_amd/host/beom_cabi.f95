@@ -89,6 +89,16 @@ module beom_cabi
       integer(c_int)           :: rc
     end function beom_sync
 
+    function beom_download_outputs(handle, h0r4, eta, u4, v4, minmax, thin_layer, errm, errm_len)      &
+             bind(C, name = 'beom_download_outputs') result(rc)
+      import :: c_int, c_ptr, c_char
+      type(c_ptr), value       :: handle, h0r4, eta, u4, v4, minmax
+      integer(c_int)           :: thin_layer
+      character(kind = c_char) :: errm(*)
+      integer(c_int), value    :: errm_len
+      integer(c_int)           :: rc
+    end function beom_download_outputs
+
     function beom_is_dense(handle) bind(C, name = 'beom_is_dense') result(rc)
       import :: c_int, c_ptr
       type(c_ptr), value :: handle

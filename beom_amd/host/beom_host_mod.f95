@@ -28,7 +28,10 @@ module private_mod
     nudg(:,:), fnud(:,:,:), hdot(:,:), tide(:,:,:,:), bodf(:,:), taus(:,:),           &
     hlay(:,:), u(:,:), v(:,:), h_u(:,:), h_v(:,:), rs_h(:,:,:), dmdx(:,:,:),          &
     dmdy(:,:,:), v_cc(:,:), v_ll(:,:), tt3d(:,:,:), tb3d(:,:,:), tu3d(:,:,:)
-  real(r4), allocatable :: h0r4(:,:)              ! what h_0.bin holds (ndeg, nlay)
+  real(r4), allocatable, target :: h0r4(:,:)      ! what h_0.bin holds (ndeg, nlay)
+  real(r4), allocatable, target :: rec_eta(:,:), rec_u(:,:), rec_v(:,:)   ! records formed on the GPU
+  real(c_double), allocatable, target :: mnmx(:,:) ! (6, nlay): min/max of h, u, v per layer
+  logical  :: h0_on_gpu = .false.
   integer,  allocatable :: posc(:)
   real(rw) :: w_ti(1), invf, ctim
   real(r8) :: tres
@@ -773,6 +776,45 @@ subroutine write_outputs()
   end do
 end subroutine write_outputs
 
+! Output record prepared on the device (beom_download_outputs): eta inversion, real*4
+! conversion, min/max and the thin-layer scan of write_outputs (:2769-2808) without moving
+! the FP64 state to the host.
+subroutine write_outputs_from_gpu()
+  character(kind = c_char) :: cmsg(lstr + 1)
+  integer(c_int) :: rc, thin
+  integer  :: unum, ios, k
+  character(9) :: txt
+  type(c_ptr) :: p_h0
+  if ( .not. allocated(rec_eta) ) allocate( rec_eta(ndeg, nlay), rec_u(ndeg, nlay), rec_v(ndeg, nlay), mnmx(6, nlay) )
+  cmsg = c_null_char
+  p_h0 = c_null_ptr
+  if ( .not. h0_on_gpu ) p_h0 = c_loc(h0r4)
+  thin = 0
+  rc = beom_download_outputs( gpu, p_h0, c_loc(rec_eta), c_loc(rec_u), c_loc(rec_v), c_loc(mnmx), thin, &
+                              cmsg, int(lstr, c_int) )
+  call gpu_check( rc, cmsg, 'beom_download_outputs' )
+  h0_on_gpu = .true.
+  call put_record_r4( 'eta_.bin', out_rec, rec_eta, .false. )
+  call put_record_r4( 'u___.bin', out_rec, rec_u,   .false. )
+  call put_record_r4( 'v___.bin', out_rec, rec_v,   .false. )
+  unum = get_un()
+  open( unit = unum, file = trim(odir) // 'time.txt', form = 'formatted', action = 'write', status = 'old', &
+        position = 'append', iostat = ios )
+  write( unum, * ) real(ctim, r8)
+  close( unum )
+  out_rec = out_rec + 1
+  write(ioso, *) 'ctim = ', ctim, ' days; dt_s = ', dt_s, ' days; record = ', out_rec - 1
+  do k = 1, nlay
+    write(ioso, *) 'min/max h', k, '= ', real(mnmx(1, k), rw), real(mnmx(2, k), rw)
+    write(ioso, *) 'min/max u', k, '= ', real(mnmx(3, k), rw), real(mnmx(4, k), rw)
+    write(ioso, *) 'min/max v', k, '= ', real(mnmx(5, k), rw), real(mnmx(6, k), rw)
+  end do
+  if ( thin > 0 ) then
+    write(txt, '(1i8)') thin
+    call fail( -int(thin), 'layer number ' // trim(txt) // ' has its thickness < hmin; Calculation halted.' )
+  end if
+end subroutine write_outputs_from_gpu
+
 subroutine write_field(var, fresh)                               ! write_array (:2817-3001)
   character(4), intent(in) :: var
   logical, intent(in)      :: fresh
@@ -908,12 +950,16 @@ subroutine advance()
                     real(dt_r, c_double), real(rsta, c_double), int(n_3d, c_int), cmsg, int(lstr, c_int) )
     call gpu_check( rc, cmsg, 'beom_step' )
     if ( mod(last, notp) == 0 ) then
-      rc = beom_download_state( gpu, c_loc(hlay), c_loc(u), c_loc(v), c_null_ptr, c_null_ptr, c_null_ptr, &
-                                c_null_ptr, c_null_ptr, c_null_ptr, c_null_ptr, c_null_ptr, c_null_ptr,  &
-                                c_null_ptr, cmsg, int(lstr, c_int) )
-      call gpu_check( rc, cmsg, 'beom_download_state' )
       ctim = real( tres + dtd8 * real(last, r8), rw )
-      call write_outputs()
+      if ( diag > 0.5_rw ) then                                  ! pvor/mont/v_cc are diagnosed on the host
+        rc = beom_download_state( gpu, c_loc(hlay), c_loc(u), c_loc(v), c_null_ptr, c_null_ptr, c_null_ptr, &
+                                  c_null_ptr, c_null_ptr, c_null_ptr, c_null_ptr, c_null_ptr, c_null_ptr,  &
+                                  c_null_ptr, cmsg, int(lstr, c_int) )
+        call gpu_check( rc, cmsg, 'beom_download_state' )
+        call write_outputs()
+      else
+        call write_outputs_from_gpu()                            ! only real*4 records cross PCIe
+      end if
     end if
     first = last + 1
   end do

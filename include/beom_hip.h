@@ -111,6 +111,16 @@ int beom_download_state(beom_handle h,
                         double *tt3d, double *tb3d, double *tu3d,
                         char *errm, int errm_len);
 
+/* Output preparation on the device: replaces the array work of write_array for 'eta_', 'u___',
+ * 'v___' (private_mod.f95:2848-2883; eta = interface elevation accumulated bottom-up in real*4)
+ * and the scans of write_outputs (:2772-2808).  h0r4 = the (ndeg, nlay) real*4 content of
+ * h_0.bin (needed on the first call, may be NULL afterwards); eta/u4/v4 = (ndeg, nlay) real*4
+ * host records (any may be NULL); minmax[nlay][6] = min/max of h over wet cells, of u and of v
+ * over their points (over all cells 0..ndeg if a mask is empty, :2776-2793); *thin_layer = first
+ * layer with a wet cell thinner than 0.5*hmin, or 0 (:2798-2808). */
+int beom_download_outputs(beom_handle h, const float *h0r4, float *eta, float *u4, float *v4,
+                          double *minmax, int *thin_layer, char *errm, int errm_len);
+
 /* The six per-layer diagnostics of update_mont_rvor_pvor_dive_kine, which the library
  * keeps per layer: each is (0:ndeg, nlay).  (The reference keeps (0:ndeg) and reuses it
  * layer after layer, private_mod.f95:48-61.) */

@@ -397,3 +397,36 @@ def test_overlapped_streams_two_slabs_one_process():
             assert same(st[k][:, la:lb], ref[k][:, ga:gb]), (g.rank, k)
         r.engine.close()
     whole.close()
+
+
+@pytest.mark.parametrize("name", ["sill_4l_ocrp", "soliton_31x15_xper", "island_3l_forced"])
+def test_device_side_output_records(name):
+    """beom_download_outputs == the host-side write_array arithmetic (:2848-2883) and scans
+    (:2772-2808) applied to the downloaded FP64 state."""
+    g = Golden(name)
+    f = _fields(g)
+    e = capi.Engine(f, variant=g.variant)
+    e.step(1, 7)
+    st = e.download(("hlay", "u", "v"))
+    h0r4 = np.ascontiguousarray(f.h_0[:, 1:].astype(np.float32))
+    eta, u4, v4, mm, thin = e.download_outputs(h0r4)
+    nl = g.p.nlay
+    ref = np.zeros_like(eta)
+    for k in range(nl - 1, -1, -1):
+        d = st["hlay"][k, 1:] - h0r4[k].astype(np.float64)
+        ref[k] = d.astype(np.float32) if k == nl - 1 else (d + ref[k + 1].astype(np.float64)).astype(np.float32)
+    assert np.array_equal(eta.view(np.uint32), ref.view(np.uint32))
+    assert np.array_equal(u4.view(np.uint32), st["u"][:, 1:].astype(np.float32).view(np.uint32))
+    assert np.array_equal(v4.view(np.uint32), st["v"][:, 1:].astype(np.float32).view(np.uint32))
+    wet = f.mk_n > 0.5
+    for k in range(nl):
+        assert mm[k, 0] == st["hlay"][k][wet].min() and mm[k, 1] == st["hlay"][k][wet].max()
+        mu = f.mk_u > 0.5 if (f.mk_u > 0.5).any() else np.ones_like(wet)
+        mv = f.mk_v > 0.5 if (f.mk_v > 0.5).any() else np.ones_like(wet)
+        assert mm[k, 2] == st["u"][k][mu].min() and mm[k, 3] == st["u"][k][mu].max()
+        assert mm[k, 4] == st["v"][k][mv].min() and mm[k, 5] == st["v"][k][mv].max()
+    assert thin == 0
+    # second call without h_0 (cached on the device) gives the same records
+    eta2, _, _, _, _ = e.download_outputs(None)
+    assert np.array_equal(eta2.view(np.uint32), eta.view(np.uint32))
+    e.close()
