@@ -103,6 +103,7 @@ def load(path: Optional[str] = None) -> C.CDLL:
     lib.beom_sync.argtypes = [H, cp, ci]
     lib.beom_set_stream.argtypes = [H, C.c_void_p, ci]
     lib.beom_set_option.argtypes = [H, cp, ci]
+    lib.beom_set_open_boundaries.argtypes = [H, ci, ipp, cp, ci]
     lib.beom_download_outputs.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, dpp, C.POINTER(ci), cp, ci]
     lib.beom_step_phase.argtypes = [H, ci, cd, cd, cd, cd, ci, ci, cp, ci]
     lib.beom_pack_rows.argtypes = [H, ci, ci, C.c_void_p]
@@ -126,7 +127,7 @@ def load(path: Optional[str] = None) -> C.CDLL:
                  "beom_update_u", "beom_update_v", "beom_rebuild_fluxes", "beom_distribute_stress",
                  "beom_device_field", "beom_is_dense", "beom_profile_steps", "beom_set_stream",
                  "beom_profile_start", "beom_profile_stop", "beom_set_option", "beom_step_phase",
-                 "beom_pack_rows", "beom_unpack_rows", "beom_download_outputs"):
+                 "beom_pack_rows", "beom_unpack_rows", "beom_download_outputs", "beom_set_open_boundaries"):
         getattr(lib, name).restype = ci
     if lib.beom_abi_version() != BEOM_ABI_VERSION:
         raise RuntimeError("ABI mismatch")
@@ -140,7 +141,8 @@ EXPORTS = ("beom_abi_version", "beom_device_count", "beom_create", "beom_destroy
            "beom_update_viscosity", "beom_update_u", "beom_update_v", "beom_rebuild_fluxes",
            "beom_distribute_stress", "beom_device_field", "beom_is_dense", "beom_profile_steps",
            "beom_set_stream", "beom_profile_start", "beom_profile_stop", "beom_set_option",
-           "beom_step_phase", "beom_pack_rows", "beom_unpack_rows", "beom_download_outputs")
+           "beom_step_phase", "beom_pack_rows", "beom_unpack_rows", "beom_download_outputs",
+           "beom_set_open_boundaries")
 
 STATE_NAMES = ("hlay", "u", "v", "h_u", "h_v", "rs_h", "dmdx", "dmdy", "v_cc", "v_ll",
                "tt3d", "tb3d", "tu3d")
@@ -171,6 +173,9 @@ class Engine:
             opt("hdot"), opt("tide"), opt("bodf"), _dp(f.taus),
             C.byref(self.h), self._err, ERRLEN)
         self._check(rc)
+        if f.flag_nudging and float(f.p.mcbc) < 0.5 and f.segm is not None:     # no_gradient_obc (:2613)
+            seg = np.ascontiguousarray(f.segm, dtype=np.int32)
+            self._check(self.lib.beom_set_open_boundaries(self.h, seg.shape[1], _ip(seg), self._err, ERRLEN))
         if upload:
             self.upload(**{k: getattr(f, k) for k in STATE_NAMES})
 

@@ -38,6 +38,8 @@ struct DevView {
     double *pcd, *qlr;
     int keep_diag;                // fused sweep also stores rvor, dive, v_cc, v_ll
     int dbg;                      // ablation switches for traffic attribution (env BEOM_DBG; 0 in production)
+    // nudged open-boundary segments, Fortran segm(nseg, 18) (no_gradient_obc, :2613-2679)
+    const int32_t *segm; int nseg;
     // stress work arrays
     double *layt, *layb, *layu, *taub, *taum;
     // constants by value

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -51,6 +52,7 @@ struct beom_engine {
     float *h0r4_dev = nullptr, *out4[3] = {nullptr, nullptr, nullptr};   // device-side output staging
     double *scan_dev = nullptr;
     int any_u = 0, any_v = 0;
+    bool obc = false;                  // no_gradient_obc active (flag_nudging, mcbc < 0.5, segments set)
     bool fuse = true;                  // dense frames: Montgomery+Leith in one sweep (k_mont_visc)
     bool fuse_uv = true;               // dense frames: update_u + update_v in one sweep (k_uv_fused)
     char last_err[512] = {0};
@@ -146,7 +148,6 @@ int beom_create(const beom_params *prm, int device, const int32_t *neig, const i
     if (prm->nlay < 1 || prm->nlay > BEOM_MAX_LAYERS || prm->ndeg < 1 || prm->lm < 1 || prm->mm < 1) { set_err(errm, errm_len, "beom_create: bad sizes"); return -3; }
     if (prm->svis > 0.0) { set_err(errm, errm_len, "beom_create: svis > 0 (biharmonic viscosity, private_mod.f95:2508-2599) is not implemented on the GPU path"); return -4; }
     if (prm->rgld > 0.5) { set_err(errm, errm_len, "beom_create: rgld = 1 (rigid lid, private_mod.f95:1705-1838) is not implemented on the GPU path"); return -5; }
-    if (prm->flag_nudging && prm->mcbc < 0.5) { set_err(errm, errm_len, "beom_create: mcbc = 0 with nudging (no_gradient_obc, private_mod.f95:2613-2679) is not implemented on the GPU path"); return -6; }
     if (prm->variant == 1 && prm->nlay < 3) { set_err(errm, errm_len, "beom_create: variant 1 (private_mod3d.f95) needs nlay >= 3"); return -7; }
     if (!neig || !subc || !mk_u || !mk_v || !mk_n || !mkpe || !mkpi || !fcor || !h_th || !nudg || !fnud) { set_err(errm, errm_len, "beom_create: null static array"); return -1; }
     int ndev = 0;
@@ -552,6 +553,11 @@ static void one_step(beom_engine *E, int tstp, const StepScalars &s) {
         launch_uv<true>(E, 0, s.gene, s.ramp, s.ctim, prod);
         if (T) T->end();
     }
+    if (E->obc) {                                                  // :2201-2204, 2285-2288
+        const dim3 g((unsigned)((E->d.nseg + BEOM_BLOCK - 1) / BEOM_BLOCK), (unsigned)E->d.nlay, 1);
+        hipLaunchKernelGGL(k_no_gradient_obc, g, dim3(BEOM_BLOCK), 0, E->stream, E->d, 0);
+        hipLaunchKernelGGL(k_no_gradient_obc, g, dim3(BEOM_BLOCK), 0, E->stream, E->d, 1);
+    }
 }
 
 extern "C" {
@@ -560,6 +566,7 @@ int beom_step(beom_handle E, int tstp_first, int nsteps, double tres, double dtd
               double rsta, int n_3d, char *errm, int errm_len) {
     if (!E) { set_err(errm, errm_len, "null handle"); return -1; }
     if (tstp_first < 1 || nsteps < 0 || n_3d < 1) { set_err(errm, errm_len, "beom_step: bad arguments"); return -3; }
+    if (E->P.flag_nudging && E->P.mcbc < 0.5 && !E->obc) { set_err(errm, errm_len, "beom_step: mcbc = 0 with nudging needs beom_set_open_boundaries (no_gradient_obc, private_mod.f95:2613-2679)"); return -6; }
     HIP_TRY(hipSetDevice(E->device));
     for (int tstp = tstp_first; tstp < tstp_first + nsteps; ++tstp)
         one_step(E, tstp, step_scalars(E, tstp, tres, dtd8, dt_r, rsta, n_3d));
@@ -622,7 +629,7 @@ int beom_step_phase(beom_handle E, int tstp, double tres, double dtd8, double dt
     const StepScalars s = step_scalars(E, tstp, tres, dtd8, dt_r, rsta, n_3d);
     const bool south = d.slab && d.joff > 0, north = d.slab && d.joff + d.M < d.Mg;
     if (!(s.fused && s.fused_uv) || s.first3 || (s.stress && (E->wind || E->bot || E->top)) ||
-        !(south || north) || d.M < 32 || (phase != 1 && phase != 2)) {
+        !(south || north) || d.M < 32 || (phase != 1 && phase != 2) || E->obc) {
         set_err(errm, errm_len, "beom_step_phase: split step not available for this step/configuration");
         return -20;
     }
@@ -727,6 +734,43 @@ int beom_download_outputs(beom_handle E, const float *h0r4, float *eta, float *u
     }
     HIP_TRY(hipStreamSynchronize(E->stream));
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// Replaces index_boundary_points' product (private_mod.f95:1060-1240): the table segm(nseg, 18)
+// of nudged open-boundary segments, Fortran storage.  Activates no_gradient_obc after the
+// momentum sweeps of every step when flag_nudging and mcbc < 0.5 (:2201-2204, 2285-2288).
+int beom_set_open_boundaries(beom_handle E, int nseg, const int32_t *segm, char *errm, int errm_len) {
+    if (!E || nseg < 1 || !segm) { set_err(errm, errm_len, "beom_set_open_boundaries: bad arguments"); return -1; }
+    HIP_TRY(hipSetDevice(E->device));
+    if (E->d.slab) { set_err(errm, errm_len, "beom_set_open_boundaries: not available on a j-slab"); return -6; }
+    auto S = [&](int is, int col) { return segm[(size_t)is + (size_t)nseg * (col - 1)]; };
+    // The reference loops are serial.  A parallel pass is equivalent iff nothing it writes is read
+    // or written by another segment of the same pass: check (component, cell) sets.
+    for (int pass = 0; pass < 2; ++pass) {
+        std::vector<long long> wr, rd;
+        for (int is = 0; is < nseg; ++is) {
+            const bool ns = S(is, 5) == 1, ew = S(is, 4) == 1;
+            const int comp = pass == 0 ? (ns ? 0 : (ew ? 1 : -1)) : (ns ? 1 : (ew ? 0 : -1));
+            if (comp < 0) continue;
+            const int ip = pass == 0 ? S(is, 10) : S(is, 1), in = pass == 0 ? S(is, 16) : S(is, 13);
+            if (ip < 1 || ip > E->d.ndeg || in < 0 || in > E->d.ndeg) { set_err(errm, errm_len, "beom_set_open_boundaries: index out of range"); return -3; }
+            wr.push_back(2ll * ip + comp);
+            rd.push_back(2ll * in + comp);
+        }
+        std::vector<long long> w2 = wr;
+        std::sort(w2.begin(), w2.end());
+        if (std::adjacent_find(w2.begin(), w2.end()) != w2.end()) { set_err(errm, errm_len, "beom_set_open_boundaries: two segments update the same point (serial order would matter)"); return -7; }
+        for (long long r : rd)
+            if (std::binary_search(w2.begin(), w2.end(), r)) { set_err(errm, errm_len, "beom_set_open_boundaries: a segment reads a point another segment updates in the same pass (serial order would matter)"); return -7; }
+    }
+    int32_t *dev = nullptr;
+    HIP_TRY(hipMalloc((void **)&dev, (size_t)nseg * 18 * sizeof(int32_t)));
+    E->allocs.push_back(dev);
+    HIP_TRY(hipMemcpy(dev, segm, (size_t)nseg * 18 * sizeof(int32_t), hipMemcpyHostToDevice));
+    E->d.segm = dev;
+    E->d.nseg = nseg;
+    E->obc = E->P.flag_nudging && E->P.mcbc < 0.5;
     return 0;
 }
 

@@ -972,3 +972,37 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_out_scan(DevView d, int any_u, i
         __syncthreads();
     }
 }
+
+// ---- no_gradient_obc, private_mod.f95:2613-2679: vanishing normal derivative of the velocity
+//      at nudged open boundaries.  pass 0 = tangential component at the wet boundary cell
+//      (:2624-2651), pass 1 = normal component at the boundary point (:2657-2678).  One thread
+//      per (segment, layer); beom_set_open_boundaries checked that no thread of a pass reads a
+//      value another thread of the same pass writes (the reference loops are serial). ----------
+__global__ __launch_bounds__(BEOM_BLOCK) void k_no_gradient_obc(DevView d, int pass) {
+    const int is = blockIdx.x * BEOM_BLOCK + threadIdx.x;
+    const int ilay = blockIdx.y + 1;
+    if (is >= d.nseg) return;
+#define SEG(col) d.segm[(long long)is + (long long)d.nseg * ((col) - 1)]
+    const bool ns = SEG(5) == 1, ew = SEG(4) == 1;       // northern/southern | eastern/western boundary
+    const int ipnt = pass == 0 ? SEG(10) : SEG(1);
+    const int in = pass == 0 ? SEG(16) : SEG(13);
+    // which component: pass 0 -> u on N/S boundaries, v on E/W; pass 1 -> v on N/S, u on E/W
+    const bool do_u = pass == 0 ? ns : (!ns && ew);
+    const bool do_v = pass == 0 ? (!ns && ew) : ns;
+    if (do_u) {
+        const double mk = d.mk_u[ipnt];
+        if (pass == 1 || mk > 0.5) {
+            const double un = LL(d.u, in, ilay) - FNUD_(in, ilay, 2) + FNUD_(ipnt, ilay, 2);
+            LL(d.u, ipnt, ilay) = un;
+            LL(d.h_u, ipnt, ilay) = un * (LL(d.hlay, ipnt, ilay) + LL(d.hlay, d.neig[8ll * ipnt + 4], ilay)) / (1.0 + mk);
+        }
+    } else if (do_v) {
+        const double mk = d.mk_v[ipnt];
+        if (pass == 1 || mk > 0.5) {
+            const double vn = LL(d.v, in, ilay) - FNUD_(in, ilay, 3) + FNUD_(ipnt, ilay, 3);
+            LL(d.v, ipnt, ilay) = vn;
+            LL(d.h_v, ipnt, ilay) = vn * (LL(d.hlay, ipnt, ilay) + LL(d.hlay, d.neig[8ll * ipnt + 6], ilay)) / (1.0 + mk);
+        }
+    }
+#undef SEG
+}

@@ -54,6 +54,7 @@ class Fields:
     invf: float
     flag_nudging: bool
     has: Dict[str, bool]  # which optional input files were present
+    segm: Optional[np.ndarray] = None   # int32 [18, nseg] = Fortran segm(nseg, 18): nudged open-boundary segments
 
     @property
     def ndeg(self): return self.p.ndeg
@@ -166,6 +167,40 @@ def index_grid_points(p: Params, h_2d: np.ndarray):
     h_th[1:] = h_2d[ii + 1, jj + 1]                                                  # :753-757
     h_th[0] = h_2d[I(0), I(0)]
     return dict(neig=neig, subc=subc, posc=posc, h_th=h_th, **mk)
+
+
+def index_boundary_points(p: Params, nd: np.ndarray, h_2d: np.ndarray) -> np.ndarray:
+    """private_mod.f95:1060-1240 — the table of nudged open-boundary segments used by
+    no_gradient_obc (:2613-2679).  nd = nudg.bin content [lm+2, mm+2, 3] (real*4).
+    Returns int32 [18, nseg] (the bytes of Fortran segm(nseg, 18)); raises like the reference
+    when no segment exists."""
+    lm, mm = p.lm, p.mm
+    wet = h_2d > p.hdry                                   # offset 1: frame (i, j) -> [i+1, j+1]
+    W = lambda i, j: bool(wet[i + 1, j + 1])
+    # packed numbering exactly as in index_grid_points, WITHOUT the periodic overwrites (:1088-1097)
+    incl = wet[1:lm + 3, 1:mm + 3] | wet[0:lm + 2, 1:mm + 3] | wet[1:lm + 3, 0:mm + 2] | wet[0:lm + 2, 0:mm + 2]
+    indc = np.zeros((lm + 4, mm + 4), dtype=np.int64)
+    flat = np.zeros(incl.size, dtype=np.int64)
+    order = np.flatnonzero(incl.ravel(order="F"))
+    flat[order] = np.arange(1, order.size + 1)
+    indc[1:lm + 3, 1:mm + 3] = flat.reshape(incl.shape, order="F")
+    I = lambda i, j: int(indc[i + 1, j + 1])
+    tiny = np.finfo(np.float32).tiny
+    xopen, yopen = float(p.xper) < 0.5, float(p.yper) < 0.5
+    rows = []
+    for j in range(0, mm + 2):
+        for i in range(0, lm + 2):
+            if W(i, j) and not W(i - 1, j) and xopen and nd[i, j, IX_U] > tiny and nd[i - 1, j, IX_U] > tiny:       # west
+                rows.append([I(i, j), i, j, 1, 0, 1, I(i - 1, j), i - 1, j, I(i, j), i, j, I(i + 1, j), i + 1, j, I(i + 1, j), i + 1, j])
+            if (not W(i, j)) and W(i - 1, j) and xopen and nd[i - 1, j, IX_U] > tiny and nd[i, j, IX_U] > tiny:     # east
+                rows.append([I(i, j), i, j, 1, 0, -1, I(i, j), i, j, I(i - 1, j), i - 1, j, I(i - 1, j), i - 1, j, I(i - 2, j), i - 2, j])
+            if W(i, j) and not W(i, j - 1) and yopen and nd[i, j, IX_V] > tiny and nd[i, j - 1, IX_V] > tiny:       # south
+                rows.append([I(i, j), i, j, 0, 1, 1, I(i, j - 1), i, j - 1, I(i, j), i, j, I(i, j + 1), i, j + 1, I(i, j + 1), i, j + 1])
+            if (not W(i, j)) and W(i, j - 1) and yopen and nd[i, j - 1, IX_V] > tiny and nd[i, j, IX_V] > tiny:     # north
+                rows.append([I(i, j), i, j, 0, 1, -1, I(i, j), i, j, I(i, j - 1), i, j - 1, I(i, j - 1), i, j - 1, I(i, j - 2), i, j - 2])
+    if not rows:
+        raise ValueError("the nudged open boundary segments could not be identified.")
+    return np.ascontiguousarray(np.array(rows, dtype=np.int32).T)
 
 
 def _seq_sum(a: np.ndarray, axis: int) -> np.ndarray:
@@ -358,6 +393,7 @@ def read_input_data(p: Params, idir: Optional[str] = None,
     fnud = np.zeros((3, nlay, ndeg + 1), dtype=f8)
     nudg = np.zeros((3, ndeg + 1), dtype=f8)
     flag_nudging = False
+    segm = None
     nd = get("nudg", (lm + 2, mm + 2, 3))
     has["nudg"] = nd is not None
     ii, jj = subc[0, 1:], subc[1, 1:]
@@ -371,6 +407,8 @@ def read_input_data(p: Params, idir: Optional[str] = None,
         ok_v = (nd[ii, jj, IX_V] > f4(1e-9)) & (nd[ii, jm, IX_V] > f4(1e-9)) & (jj > 0)
         nudg[IX_V, 1:] = np.where(ok_v, nd[ii, jj, IX_V].astype(f8) * 0.5 + nd[ii, jm, IX_V].astype(f8) * 0.5, 0.0)
         flag_nudging = bool(np.any(nudg > 1e-9))
+        if flag_nudging:
+            segm = index_boundary_points(p, nd, h_2d)               # :868-871
         fnud[IX_N, :, 1:] = hlay[:, 1:]                             # :874-881
     it = get("init", (lm + 2, mm + 2, nlay, 3))
     has["init"] = it is not None
@@ -441,4 +479,4 @@ def read_input_data(p: Params, idir: Optional[str] = None,
         tt3d=np.zeros((nlay, 2, ndeg + 1), dtype=f8), tb3d=np.zeros((nlay, 2, ndeg + 1), dtype=f8),
         tu3d=np.zeros((nlay, 2, ndeg + 1), dtype=f8), taus=taus,
         fnud=fnud, nudg=nudg, hdot=hdot, tide=tide, w_ti=w_ti, bodf=bodf,
-        invf=float(invf), flag_nudging=flag_nudging, has=has)
+        invf=float(invf), flag_nudging=flag_nudging, has=has, segm=segm)

@@ -9,7 +9,7 @@
 ! (private_mod.f95) whose observable behaviour a block reproduces.
 !
 ! Not offered on the GPU path, refused with errc < 0 like any other bad option:
-! rgld = 1 (rigid lid), nudging with mcbc = 0 (no_gradient_obc).  The fork's extra
+! rgld = 1 (rigid lid).  The fork's extra
 ! switches svis/tdrg/topt are not declared by the reference's own shared_mod.f95
 ! (SURVEY F2); this host does not reference them (= 0).
 module private_mod
@@ -33,6 +33,7 @@ module private_mod
   real(c_double), allocatable, target :: mnmx(:,:) ! (6, nlay): min/max of h, u, v per layer
   logical  :: h0_on_gpu = .false.
   integer,  allocatable :: posc(:)
+  integer(c_int32_t), allocatable, target :: segm(:,:)   ! nudged open-boundary segments (nseg, 18), :1060-1240
   real(rw) :: w_ti(1), invf, ctim
   real(r8) :: tres
   logical  :: has_hdot, has_tide, has_bodf, nudging_on
@@ -498,32 +499,75 @@ subroutine load_nudging(h_2d)
   end do
   if ( any( nudg > 1.e-9_rw ) ) then
     nudging_on = .true.
-    ! index_boundary_points (:1060-1240): a nudged open-boundary segment must exist.
-    nseg = 0
-    do j = 0, mm + 1
-      do i = 0, lm + 1
-        if ( h_2d(i,j) > hdry .and. .not. h_2d(i-1,j) > hdry ) then
-          if ( c(i,j,ix_u) > tiny(0._r4) .and. c(max(i-1,0),j,ix_u) > tiny(0._r4) .and. xper < 0.5_rw ) nseg = nseg + 1
-        end if
-        if ( .not. h_2d(i,j) > hdry .and. h_2d(i-1,j) > hdry ) then
-          if ( c(max(i-1,0),j,ix_u) > tiny(0._r4) .and. c(i,j,ix_u) > tiny(0._r4) .and. xper < 0.5_rw ) nseg = nseg + 1
-        end if
-        if ( h_2d(i,j) > hdry .and. .not. h_2d(i,j-1) > hdry ) then
-          if ( c(i,j,ix_v) > tiny(0._r4) .and. c(i,max(j-1,0),ix_v) > tiny(0._r4) .and. yper < 0.5_rw ) nseg = nseg + 1
-        end if
-        if ( .not. h_2d(i,j) > hdry .and. h_2d(i,j-1) > hdry ) then
-          if ( c(i,max(j-1,0),ix_v) > tiny(0._r4) .and. c(i,j,ix_v) > tiny(0._r4) .and. yper < 0.5_rw ) nseg = nseg + 1
-        end if
-      end do
-    end do
-    if ( nseg == 0 ) call fail( -1, 'the nudged open boundary segments could not be identified.' )
-    if ( mcbc < 0.5_rw ) call fail( -6, 'mcbc = 0 (no_gradient_obc) is not available on the MI355X path.' )
+    call find_open_boundaries( h_2d, c )
   end if
   do k = 1, nlay
     fnud(1:, k, ix_n) = real( hlay(1:, k), rw )
   end do
   deallocate( a, c )
 end subroutine load_nudging
+
+! ---- index_boundary_points (:1060-1240): one row per nudged open-boundary segment; the 18
+!      columns are those of the reference (1-3 normal velocity point, 4/5 zonal/meridional
+!      flag, 6 orientation, 7-9 dry cell, 10-12 wet cell, 13-15 interior normal point,
+!      16-18 interior cell).  Two passes: count, then fill. ----------------------------------
+subroutine find_open_boundaries(h_2d, c)
+  real(rw), intent(in) :: h_2d(-1:, -1:)
+  real(r4), intent(in) :: c(0:, 0:, :)
+  integer, allocatable :: look(:,:)
+  integer :: i, j, n, pass, nseg
+  logical :: wet, wetw, wets
+  allocate( look(-1:lm+2, -1:mm+2) )
+  look = 0
+  n = 0
+  do j = 0, mm + 1
+    do i = 0, lm + 1
+      if ( h_2d(i,j) > hdry .or. h_2d(i-1,j) > hdry .or. h_2d(i,j-1) > hdry .or. h_2d(i-1,j-1) > hdry ) then
+        n = n + 1
+        look(i,j) = n
+      end if
+    end do
+  end do
+  do pass = 1, 2
+    nseg = 0
+    do j = 0, mm + 1
+      do i = 0, lm + 1
+        wet = h_2d(i,j) > hdry;  wetw = h_2d(i-1,j) > hdry;  wets = h_2d(i,j-1) > hdry
+        if ( wet .and. .not. wetw .and. xper < 0.5_rw ) then                      ! western boundary
+          if ( c(i,j,ix_u) > tiny(0._r4) .and. c(max(i-1,0),j,ix_u) > tiny(0._r4) ) then
+            nseg = nseg + 1
+            if ( pass == 2 ) segm(nseg, :) = (/ look(i,j), i, j, 1, 0, 1, look(i-1,j), i-1, j, look(i,j), i, j, &
+                                                look(i+1,j), i+1, j, look(i+1,j), i+1, j /)
+          end if
+        end if
+        if ( .not. wet .and. wetw .and. xper < 0.5_rw ) then                      ! eastern boundary
+          if ( c(max(i-1,0),j,ix_u) > tiny(0._r4) .and. c(i,j,ix_u) > tiny(0._r4) ) then
+            nseg = nseg + 1
+            if ( pass == 2 ) segm(nseg, :) = (/ look(i,j), i, j, 1, 0, -1, look(i,j), i, j, look(i-1,j), i-1, j, &
+                                                look(i-1,j), i-1, j, look(i-2,j), i-2, j /)
+          end if
+        end if
+        if ( wet .and. .not. wets .and. yper < 0.5_rw ) then                      ! southern boundary
+          if ( c(i,j,ix_v) > tiny(0._r4) .and. c(i,max(j-1,0),ix_v) > tiny(0._r4) ) then
+            nseg = nseg + 1
+            if ( pass == 2 ) segm(nseg, :) = (/ look(i,j), i, j, 0, 1, 1, look(i,j-1), i, j-1, look(i,j), i, j, &
+                                                look(i,j+1), i, j+1, look(i,j+1), i, j+1 /)
+          end if
+        end if
+        if ( .not. wet .and. wets .and. yper < 0.5_rw ) then                      ! northern boundary
+          if ( c(i,max(j-1,0),ix_v) > tiny(0._r4) .and. c(i,j,ix_v) > tiny(0._r4) ) then
+            nseg = nseg + 1
+            if ( pass == 2 ) segm(nseg, :) = (/ look(i,j), i, j, 0, 1, -1, look(i,j), i, j, look(i,j-1), i, j-1, &
+                                                look(i,j-1), i, j-1, look(i,j-2), i, j-2 /)
+          end if
+        end if
+      end do
+    end do
+    if ( nseg == 0 ) call fail( -1, 'the nudged open boundary segments could not be identified.' )
+    if ( pass == 1 ) allocate( segm(nseg, 18) )
+  end do
+  deallocate( look )
+end subroutine find_open_boundaries
 
 ! ---- init.bin (:882-910): interface anomalies -> thickness, velocities ----------------
 subroutine load_initial()
@@ -910,6 +954,10 @@ subroutine gpu_start()
                     c_loc(mkpe), c_loc(mkpi), c_loc(fcor), c_loc(h_th), c_loc(h_to), c_loc(nudg),  &
                     c_loc(fnud), p_hdot, p_tide, p_bodf, c_loc(taus), gpu, cmsg, int(lstr, c_int) )
   call gpu_check( rc, cmsg, 'beom_create' )
+  if ( nudging_on .and. mcbc < 0.5_rw ) then                     ! no_gradient_obc (:2613-2679) on the device
+    rc = beom_set_open_boundaries( gpu, int(size(segm, 1), c_int), c_loc(segm), cmsg, int(lstr, c_int) )
+    call gpu_check( rc, cmsg, 'beom_set_open_boundaries' )
+  end if
   rc = beom_upload_state( gpu, c_loc(hlay), c_loc(u), c_loc(v), c_loc(h_u), c_loc(h_v), c_loc(rs_h), &
                           c_loc(dmdx), c_loc(dmdy), c_loc(v_cc), c_loc(v_ll), c_loc(tt3d),           &
                           c_loc(tb3d), c_loc(tu3d), cmsg, int(lstr, c_int) )

@@ -92,6 +92,13 @@ int beom_create(const beom_params *prm, int device,
 
 int beom_destroy(beom_handle h);
 
+/* Replaces the product of index_boundary_points (private_mod.f95:1060-1240): segm(nseg, 18),
+ * Fortran storage segm[(iseg-1) + nseg*(col-1)], default integers.  With flag_nudging and
+ * mcbc < 0.5 the engine then applies no_gradient_obc (:2613-2679) after the momentum sweeps of
+ * every step (:2201-2204, 2285-2288); beom_step refuses such a configuration until this call
+ * has been made.  Single-GPU handles only. */
+int beom_set_open_boundaries(beom_handle h, int nseg, const int32_t *segm, char *errm, int errm_len);
+
 /* Prognostic + history state, host -> device.  Any pointer may be NULL (left as is;
  * a fresh handle holds the values of initialize_variables, private_mod.f95:252-307). */
 int beom_upload_state(beom_handle h,

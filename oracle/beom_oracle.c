@@ -30,6 +30,9 @@ typedef struct oracle_state {
     double *mont, *rvor, *pvor, *dive, *d2hx, *d2hy;
     /* optional per-layer copies of the scratch (0:ndeg, nlay) for per-layer checks; may be NULL */
     double *mont_l, *rvor_l, *pvor_l, *dive_l, *d2hx_l, *d2hy_l;
+    /* nudged open-boundary segments, Fortran segm(nseg, 18) (private_mod.f95:1060-1240); may be NULL */
+    const int32_t *segm;
+    int64_t nseg;
 } oracle_state;
 
 #define N1 ((size_t)P->ndeg + 1)
@@ -422,6 +425,39 @@ void oracle_distribute_stress(const beom_params *P, oracle_state *S) {
 #undef LY
 }
 
+/* ---- no_gradient_obc, private_mod.f95:2613-2679 (only when flag_nudging and mcbc < 0.5) ---- */
+#define SEGM(is, col) S->segm[(size_t)(is) + (size_t)S->nseg * ((col) - 1)]
+void oracle_no_gradient_obc(const beom_params *P, oracle_state *S, int ilay) {
+    for (int64_t is = 0; is < S->nseg; ++is) {                               /* :2624-2651 */
+        const int ipnt = SEGM(is, 10), in = SEGM(is, 16);
+        if (SEGM(is, 5) == 1) {
+            if (S->mk_u[ipnt] > 0.5) {
+                L2(S->u, ipnt, ilay) = L2(S->u, in, ilay) - FNUD(in, ilay, IX_U) + FNUD(ipnt, ilay, IX_U);
+                L2(S->h_u, ipnt, ilay) = L2(S->u, ipnt, ilay)
+                    * (L2(S->hlay, ipnt, ilay) + L2(S->hlay, NEIG(5, ipnt), ilay)) / (1.0 + S->mk_u[ipnt]);
+            }
+        } else if (SEGM(is, 4) == 1) {
+            if (S->mk_v[ipnt] > 0.5) {
+                L2(S->v, ipnt, ilay) = L2(S->v, in, ilay) - FNUD(in, ilay, IX_V) + FNUD(ipnt, ilay, IX_V);
+                L2(S->h_v, ipnt, ilay) = L2(S->v, ipnt, ilay)
+                    * (L2(S->hlay, ipnt, ilay) + L2(S->hlay, NEIG(7, ipnt), ilay)) / (1.0 + S->mk_v[ipnt]);
+            }
+        }
+    }
+    for (int64_t is = 0; is < S->nseg; ++is) {                               /* :2657-2678 */
+        const int ipnt = SEGM(is, 1), in = SEGM(is, 13);
+        if (SEGM(is, 5) == 1) {
+            L2(S->v, ipnt, ilay) = L2(S->v, in, ilay) - FNUD(in, ilay, IX_V) + FNUD(ipnt, ilay, IX_V);
+            L2(S->h_v, ipnt, ilay) = L2(S->v, ipnt, ilay)
+                * (L2(S->hlay, ipnt, ilay) + L2(S->hlay, NEIG(7, ipnt), ilay)) / (1.0 + S->mk_v[ipnt]);
+        } else if (SEGM(is, 4) == 1) {
+            L2(S->u, ipnt, ilay) = L2(S->u, in, ilay) - FNUD(in, ilay, IX_U) + FNUD(ipnt, ilay, IX_U);
+            L2(S->h_u, ipnt, ilay) = L2(S->u, ipnt, ilay)
+                * (L2(S->hlay, ipnt, ilay) + L2(S->hlay, NEIG(5, ipnt), ilay)) / (1.0 + S->mk_u[ipnt]);
+        }
+    }
+}
+
 /* ---- one time step: first_three_timesteps (:2151-2205) / gener_forward_backward
  *      (:2259-2290), rgld = 0, no_gradient_obc excluded (mcbc >= 0.5) ------------- */
 static void oracle_one_step(const beom_params *P, oracle_state *S, int tstp, int first3,
@@ -439,6 +475,8 @@ static void oracle_one_step(const beom_params *P, oracle_state *S, int tstp, int
             oracle_update_v(P, S, ilay, gene, ramp, ctim);
             oracle_update_u(P, S, ilay, gene, ramp, ctim);
         }
+        if (P->flag_nudging && P->mcbc < 0.5 && S->segm)                    /* :2201-2204,2285-2288 */
+            oracle_no_gradient_obc(P, S, ilay);
     }
 }
 
@@ -446,7 +484,7 @@ static void oracle_one_step(const beom_params *P, oracle_state *S, int tstp, int
 int oracle_step(const beom_params *P, oracle_state *S, int tstp_first, int nsteps,
                 double tres, double dtd8, double dt_r, double rsta, int n_3d) {
     if (P->svis > 0 || P->rgld > 0.5) return -1;
-    if (P->flag_nudging && P->mcbc < 0.5) return -2;
+    if (P->flag_nudging && P->mcbc < 0.5 && !S->segm) return -2;
     for (int tstp = tstp_first; tstp < tstp_first + nsteps; ++tstp) {
         const double ctim = tres + dtd8 * (double)tstp;                      /* :1862,1887 */
         double ramp = 1.0;

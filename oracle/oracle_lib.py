@@ -22,7 +22,8 @@ _SCR_L = tuple(k + "_l" for k in SCRATCH_NAMES)
 
 class OracleState(C.Structure):
     _fields_ = ([(k, C.c_void_p) for k in _STATIC] + [(k, C.c_void_p) for k in STATE_NAMES]
-                + [(k, C.c_void_p) for k in SCRATCH_NAMES] + [(k, C.c_void_p) for k in _SCR_L])
+                + [(k, C.c_void_p) for k in SCRATCH_NAMES] + [(k, C.c_void_p) for k in _SCR_L]
+                + [("segm", C.c_void_p), ("nseg", C.c_int64)])
 
 
 def build():
@@ -65,6 +66,7 @@ def load():
         _lib.oracle_update_v.argtypes = [PP, SP, ci, cd, cd, cd]
         _lib.oracle_rebuild_fluxes.argtypes = [PP, SP]
         _lib.oracle_distribute_stress.argtypes = [PP, SP]
+        _lib.oracle_no_gradient_obc.argtypes = [PP, SP, ci]
         _lib.oracle_step.argtypes = [PP, SP, ci, ci, cd, cd, cd, cd, ci]
         _lib.oracle_step.restype = ci
         assert _lib.oracle_sizeof_params() == C.sizeof(BeomParams)
@@ -90,10 +92,16 @@ class Oracle:
         for k in _SCR_L:
             self.a[k] = np.zeros((f.p.nlay, n1)) if per_layer_scratch else None
         self.st = OracleState()
+        self.segm = np.ascontiguousarray(f.segm, dtype=np.int32) if getattr(f, "segm", None) is not None else None
         for k, _ in OracleState._fields_:
+            if k in ("segm", "nseg"):
+                continue
             arr = self.a[k]
             present = arr is not None and (k not in ("hdot", "tide", "bodf") or f.has.get(k, True))
             setattr(self.st, k, arr.ctypes.data if present else None)
+
+        self.st.segm = self.segm.ctypes.data if self.segm is not None else None
+        self.st.nseg = self.segm.shape[1] if self.segm is not None else 0
 
     def step(self, tstp_first: int, nsteps: int, tres: float = 0.0):
         p = self.p
@@ -107,6 +115,7 @@ class Oracle:
     def update_viscosity(self, ilay): self.lib.oracle_update_viscosity(C.byref(self.prm), C.byref(self.st), ilay)
     def update_u(self, ilay, gene, ramp, ctim): self.lib.oracle_update_u(C.byref(self.prm), C.byref(self.st), ilay, gene, ramp, ctim)
     def update_v(self, ilay, gene, ramp, ctim): self.lib.oracle_update_v(C.byref(self.prm), C.byref(self.st), ilay, gene, ramp, ctim)
+    def no_gradient_obc(self, ilay): self.lib.oracle_no_gradient_obc(C.byref(self.prm), C.byref(self.st), ilay)
     def rebuild_fluxes(self): self.lib.oracle_rebuild_fluxes(C.byref(self.prm), C.byref(self.st))
     def distribute_stress(self): self.lib.oracle_distribute_stress(C.byref(self.prm), C.byref(self.st))
 

@@ -120,6 +120,32 @@ def case_3d_variant():
     return p, {"h_bo": h_bo, "nudg": nudg, "init": init}
 
 
+def case_obc():
+    """Nudged OPEN boundaries with the original BEOM treatment (mcbc = 0): no_gradient_obc
+    (private_mod.f95:2613-2679) on a western (u-normal) and a northern (v-normal) boundary."""
+    lm, mm, nlay = 30, 14, 2
+    h_bo = np.zeros((lm + 2, mm + 2)); h_bo[1:-1, 1:-1] = 120.0
+    ndeg = I.get_nbr_deg_freedom(h_bo)
+    nudg = np.zeros((lm + 2, mm + 2, 3))
+    for i in range(0, 7):                       # western sponge: eta and u (normal), margin included
+        nudg[i, :, 0] = np.maximum(nudg[i, :, 0], 0.35 * (7 - i) / 7.0)
+        nudg[i, :, 1] = np.maximum(nudg[i, :, 1], 0.35 * (7 - i) / 7.0)
+    for j in range(mm + 1, mm - 5, -1):         # northern sponge: eta and v (normal)
+        w = 0.3 * (j - (mm - 5)) / 7.0
+        nudg[:, j, 0] = np.maximum(nudg[:, j, 0], w)
+        nudg[:, j, 2] = np.maximum(nudg[:, j, 2], w)
+    x = (np.arange(lm + 2) - 18.0)[:, None]; y = (np.arange(mm + 2) - 6.0)[None, :]
+    init = np.zeros((lm + 2, mm + 2, nlay, 3))
+    init[:, :, 0, 0] = 0.5 * np.exp(-(x ** 2 + y ** 2) / 9.0)
+    init[:, :, 1, 0] = -2.0 * np.exp(-(x ** 2 + y ** 2) / 9.0)
+    init[:, :, 0, 1] = 0.02
+    cext = np.sqrt(9.8 * 120.0); dl = 3.0e3; dt = 0.5 * dl / cext
+    p = make_params(lm, mm, nlay, ndeg, dl, cext, 0.8e-4, [1025.0, 1027.5], [0.0, 0.35],
+                    12 * dt / 86400.0, 4 * dt / 86400.0, 0.0, 0.0, 0.0, 0.15, 0.0, 1.0, 10.0, 10.0, 1.0, 1.0,
+                    0.0, 0.0, 0.0, 0.0, 0.0, 0.0, desc="golden: open boundaries, mcbc = 0", mcbc="0.")
+    return p, {"h_bo": h_bo, "nudg": nudg, "init": init}
+
+
 def _std_fb(pf):
     p, f = pf
     return p.replace(g_fb="0."), f
@@ -139,6 +165,7 @@ CASES = {
     "island_3l_forced": (lambda: case_island(3), "private_mod.f95"),
     "tide_sponge": (case_tide, "private_mod.f95"),
     "variant3d_3l": (case_3d_variant, "private_mod3d.f95"),
+    "obc_mcbc0_2l": (case_obc, "private_mod.f95"),
 }
 
 

@@ -85,5 +85,7 @@ def test_oracle_sweeps_compose_to_step(name):
             order = ("u", "v") if tstp % 2 == 0 else ("v", "u")
             for w in order:
                 getattr(b, "update_" + w)(il, gene, ramp, ctim)
+            if f.flag_nudging and float(p.mcbc) < 0.5:
+                b.no_gradient_obc(il)
     for k in STATE:
         assert same(a.state()[k], b.state()[k]), k
