@@ -16,6 +16,7 @@
 struct DevView {
     // sizes
     int ndeg, nlay, lm, mm, nsal, variant;
+    int mm_glob;                  // mm of the whole frame (= mm unless the handle is a j-slab)
     long long n1;                 // ndeg + 1
     int L, M, xper, yper;         // dense closed form: L = lm+1, M = mm+1 (local rows)
     int joff, Mg, slab;           // j-slab: local row j is global row j + joff of Mg = mm_global+1 rows
@@ -38,6 +39,8 @@ struct DevView {
     double *pcd, *qlr;
     int keep_diag;                // fused sweep also stores rvor, dive, v_cc, v_ll
     int dbg;                      // ablation switches for traffic attribution (env BEOM_DBG; 0 in production)
+    // biharmonic viscosity (svis > 0, :2508-2599): Laplacians and thickness-weighted fluxes
+    double *delu, *delv, *uu4, *vv4; double svis;
     // nudged open-boundary segments, Fortran segm(nseg, 18) (no_gradient_obc, :2613-2679)
     const int32_t *segm; int nseg;
     // stress work arrays

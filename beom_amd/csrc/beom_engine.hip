@@ -146,7 +146,7 @@ int beom_create(const beom_params *prm, int device, const int32_t *neig, const i
     if (!prm || !out) { set_err(errm, errm_len, "beom_create: null argument"); return -1; }
     if (prm->abi_version != BEOM_ABI_VERSION) { set_err(errm, errm_len, "beom_create: ABI version mismatch (%d vs %d)", prm->abi_version, BEOM_ABI_VERSION); return -2; }
     if (prm->nlay < 1 || prm->nlay > BEOM_MAX_LAYERS || prm->ndeg < 1 || prm->lm < 1 || prm->mm < 1) { set_err(errm, errm_len, "beom_create: bad sizes"); return -3; }
-    if (prm->svis > 0.0) { set_err(errm, errm_len, "beom_create: svis > 0 (biharmonic viscosity, private_mod.f95:2508-2599) is not implemented on the GPU path"); return -4; }
+    if (prm->svis > 0.0 && prm->slab_mm > 0) { set_err(errm, errm_len, "beom_create: svis > 0 (biharmonic viscosity) is not available on a j-slab"); return -4; }
     if (prm->rgld > 0.5) { set_err(errm, errm_len, "beom_create: rgld = 1 (rigid lid, private_mod.f95:1705-1838) is not implemented on the GPU path"); return -5; }
     if (prm->variant == 1 && prm->nlay < 3) { set_err(errm, errm_len, "beom_create: variant 1 (private_mod3d.f95) needs nlay >= 3"); return -7; }
     if (!neig || !subc || !mk_u || !mk_v || !mk_n || !mkpe || !mkpi || !fcor || !h_th || !nudg || !fnud) { set_err(errm, errm_len, "beom_create: null static array"); return -1; }
@@ -168,7 +168,8 @@ int beom_create(const beom_params *prm, int device, const int32_t *neig, const i
     d.epsi = prm->epsi; d.gamm = prm->gamm; d.del1 = prm->del1; d.del2 = prm->del2; d.hmin = prm->hmin;
     d.hsal = prm->hsal; d.bvis = prm->bvis; d.dvis = prm->dvis; d.bdrg = prm->bdrg; d.tdrg = prm->tdrg;
     d.qdrg = prm->qdrg; d.hsbl = prm->hsbl; d.hbbl = prm->hbbl; d.uadv = prm->uadv; d.ocrp = prm->ocrp;
-    d.rgld = prm->rgld; d.invf = prm->invf; d.w_ti = prm->w_ti;
+    d.rgld = prm->rgld; d.invf = prm->invf; d.w_ti = prm->w_ti; d.svis = prm->svis;
+    d.mm_glob = prm->slab_mm > 0 ? prm->slab_mm : prm->mm;
     for (int i = 0; i < BEOM_MAX_LAYERS; ++i) d.rhon[i] = prm->rhon[i];
     d.i_dl = 1.0 / prm->dl;                      // private_mod.f95:1428,1511,1599,2321
     d.i_gr = 1.0 / prm->grav;                    // :2322
@@ -230,6 +231,7 @@ int beom_create(const beom_params *prm, int device, const int32_t *neig, const i
     AL(tt3d, 2 * nl * n1) AL(tb3d, 2 * nl * n1) AL(tu3d, 2 * nl * n1)
     AL(pcd, nl * n1) AL(qlr, nl * n1)
     AL(mont, nl * n1) AL(rvor, nl * n1) AL(pvor, nl * n1) AL(dive, nl * n1) AL(d2hx, nl * n1) AL(d2hy, nl * n1)
+    if (prm->svis > 0.0) { AL(delu, nl * n1) AL(delv, nl * n1) AL(uu4, nl * n1) AL(vv4, nl * n1) }
     if (E->wind) AL(layt, nl * n1)
     if (E->bot) { AL(layb, nl * n1) AL(taub, 2 * n1) }
     if (E->top) { AL(layu, nl * n1) AL(taum, 2 * n1) }
@@ -419,6 +421,11 @@ static void launch_mont(beom_engine *E, int ilay) {
 static void launch_visc(beom_engine *E, int ilay) {
     const int nz = ilay ? 1 : E->d.nlay;
     LAUNCH_CTX(k_update_visc<CellGather>, k_update_visc<CellDense>, nz, E->d, ilay);
+    if (E->d.svis > 0.0) {                         // biharmonic part of update_viscosity (:2508-2599)
+        const dim3 g = ilay ? E->grid_cells0 : E->grid_cells_layers_flat;
+        hipLaunchKernelGGL(k_biharm_lap, g, dim3(BEOM_BLOCK), 0, E->stream, E->d, ilay);
+        hipLaunchKernelGGL(k_biharm_flux, g, dim3(BEOM_BLOCK), 0, E->stream, E->d, ilay);
+    }
 }
 template <bool XDIR>
 static void launch_uv(beom_engine *E, int ilay, double gene, double ramp, double ctim, bool prod = false) {
@@ -461,7 +468,7 @@ static void launch_uv_fused(beom_engine *E, bool first_x, bool prod, double gene
 static bool can_fuse(const beom_engine *E, int n_3d) {
     // every step must refresh the viscosity (else v_cc/v_ll have to persist): dvis > 1e-3 and n_3d = 1 (:2268)
     const int nl = E->d.nlay;
-    return E->dense && E->fuse && E->P.dvis > 1.e-3 && n_3d == 1 && (nl <= 6 || nl == 8);
+    return E->dense && E->fuse && E->P.dvis > 1.e-3 && n_3d == 1 && (nl <= 6 || nl == 8) && !(E->P.svis > 0.0);
 }
 static void launch_stress(beom_engine *E) {
     if (!(E->wind || E->bot || E->top)) return;
@@ -508,7 +515,7 @@ static StepScalars step_scalars(const beom_engine *E, int tstp, double tres, dou
     }
     s.gene = s.first3 ? 0.0 : E->P.g_fb;                           // :1859,1877
     s.fused = can_fuse(E, n_3d);
-    s.fused_uv = E->dense && E->fuse_uv;
+    s.fused_uv = E->dense && E->fuse_uv && !(E->P.svis > 0.0);
     return s;
 }
 
@@ -530,7 +537,7 @@ static void one_step(beom_engine *E, int tstp, const StepScalars &s) {
     const bool prod = s.fused && launch_mont_visc(E);              // :2187-2188, 2266-2269 in one sweep
     if (!prod) launch_mont(E, 0);
     if (T) T->end();
-    if (!prod && (s.first3 || (E->P.dvis > 1.e-3 && s.upst))) {     // :2188,2268
+    if (!prod && (s.first3 || (E->P.dvis > 1.e-3 && s.upst) || E->P.svis > 0.0)) {     // :2188,2268
         if (T) T->begin(2);
         launch_visc(E, 0);
         if (T) T->end();

@@ -572,7 +572,13 @@ __device__ __forceinline__ double uv_core(const C &c, const DevView &d, int ilay
         rhsi = rhsi + (d.del1 * dmd4 + d.del2 * LL(io.dm2, ipnt, ilay) + d.gamm * LL(io.dm1, ipnt, ilay)
                        + d.epsi * LL(io.dm0, ipnt, ilay)) * gene;
     }
-    if (PROD) {       // products staged by k_mont_visc: pcd = v_cc*dive, qlr = v_ll*rvor
+    if (d.svis > 0.0) {   // biharmonic form (:1471-1473, :1555-1557); the u form rounds to default real
+        const double i__h = 1.0 / (hcen + 1.0 - mask);
+        if (XDIR) rhsi = rhsi - d.svis * i_dl * (double)(float)(LL(d.uu4, ipnt, ilay) - LL(d.uu4, cb, ilay)
+                                                               + LL(d.vv4, ca, ilay) - LL(d.vv4, ipnt, ilay)) * i__h;
+        else      rhsi = rhsi - d.svis * i_dl * (LL(d.vv4, ca, ilay) - LL(d.vv4, ipnt, ilay)
+                                                - LL(d.uu4, ipnt, ilay) + LL(d.uu4, cb, ilay)) * i__h;
+    } else if (PROD) {       // products staged by k_mont_visc: pcd = v_cc*dive, qlr = v_ll*rvor
         const double p0 = sh.pcd_s(), pb = sh.pcd_b();
         const double l0 = sh.qlr_s(), la = sh.qlr_a();
         if (XDIR) rhsi = rhsi + (p0 - pb) * i_dl - (la - l0) * i_dl;
@@ -1005,4 +1011,53 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_no_gradient_obc(DevView d, int p
         }
     }
 #undef SEG
+}
+
+// ---- biharmonic viscosity, update_viscosity's svis > 0 part (private_mod.f95:2508-2599).
+//      A fork-specific option outside every BASELINE configuration: always via the neig/mask
+//      tables, five separate sweeps.  The reference rounds two expressions to DEFAULT real
+//      (`real(x)` without a kind, :2565 and :1472); so do we. ------------------------------------
+__global__ __launch_bounds__(BEOM_BLOCK) void k_biharm_lap(DevView d, int ilay0) {             // :2508-2550
+    const int ipnt = blockIdx.x * BEOM_BLOCK + threadIdx.x + 1;
+    const int ilay = ilay0 ? ilay0 : (int)blockIdx.y + 1;
+    if (ipnt > d.ndeg) return;
+    const int32_t *nb = d.neig + 8ll * ipnt;
+    const int c1 = nb[0], c3 = nb[2], c5 = nb[4], c7 = nb[6];
+    const double dl = d.dl;
+    double du = 0.0, dv = 0.0;
+    if (d.mk_u[ipnt] > 0.5) {
+        du = du + 1.0 / (dl * dl) * (d.mk_u[c1] * LL(d.u, c1, ilay) + d.mk_u[c3] * LL(d.u, c3, ilay)
+                                     + d.mk_u[c5] * LL(d.u, c5, ilay) + d.mk_u[c7] * LL(d.u, c7, ilay));
+        du = du - 1.0 / (dl * dl) * (d.mk_u[c1] + d.mk_u[c3] + d.mk_u[c5] + d.mk_u[c7]) * LL(d.u, ipnt, ilay);
+    }
+    if (d.mk_v[ipnt] > 0.5) {
+        dv = dv + 1.0 / (dl * dl) * (d.mk_v[c1] * LL(d.v, c1, ilay) + d.mk_v[c3] * LL(d.v, c3, ilay)
+                                     + d.mk_v[c5] * LL(d.v, c5, ilay) + d.mk_v[c7] * LL(d.v, c7, ilay));
+        dv = dv - 1.0 / (dl * dl) * (d.mk_v[c1] + d.mk_v[c3] + d.mk_v[c5] + d.mk_v[c7]) * LL(d.v, ipnt, ilay);
+    }
+    LL(d.delu, ipnt, ilay) = du;
+    LL(d.delv, ipnt, ilay) = dv;
+}
+__global__ __launch_bounds__(BEOM_BLOCK) void k_biharm_flux(DevView d, int ilay0) {            // :2557-2598
+    const int ipnt = blockIdx.x * BEOM_BLOCK + threadIdx.x + 1;
+    const int ilay = ilay0 ? ilay0 : (int)blockIdx.y + 1;
+    if (ipnt > d.ndeg) return;
+    const int32_t *nb = d.neig + 8ll * ipnt;
+    const int c1 = nb[0], c3 = nb[2], c5 = nb[4], c6 = nb[5], c7 = nb[6];
+    const double dl = d.dl;
+    const double h = LL(d.hlay, ipnt, ilay);
+    const double hh_q = (double)(float)(h + d.mk_n[c5] * LL(d.hlay, c5, ilay) + d.mk_n[c6] * LL(d.hlay, c6, ilay)
+                                        + d.mk_n[c7] * LL(d.hlay, c7, ilay))
+                        / (1.0 + d.mk_n[c5] + d.mk_n[c6] + d.mk_n[c7]);
+    double uu = 0.0, vv = 0.0;
+    uu = uu - 1.0 / dl * h * LL(d.delu, ipnt, ilay) + 1.0 / dl * h * LL(d.delv, ipnt, ilay);
+    vv = vv + 1.0 / dl * hh_q * LL(d.delu, ipnt, ilay) + 1.0 / dl * hh_q * LL(d.delv, ipnt, ilay);
+    const int si = d.subc[ipnt], sj = d.subc[ipnt + d.n1];
+    if (si <= d.lm - 1) uu = uu + 1.0 / dl * h * LL(d.delu, c1, ilay);
+    if (sj <= d.mm_glob - 1) uu = uu - 1.0 / dl * h * LL(d.delv, c3, ilay);
+    if (si > 1) vv = vv - 1.0 / dl * hh_q * LL(d.delv, c5, ilay);
+    if (sj > 1) vv = vv - 1.0 / dl * hh_q * LL(d.delu, c7, ilay);
+    if (d.mk_u[ipnt] * d.mk_v[ipnt] < 0.5) vv = 0.0;
+    LL(d.uu4, ipnt, ilay) = uu;
+    LL(d.vv4, ipnt, ilay) = vv;
 }

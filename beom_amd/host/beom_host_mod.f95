@@ -11,7 +11,18 @@
 ! Not offered on the GPU path, refused with errc < 0 like any other bad option:
 ! rgld = 1 (rigid lid).  The fork's extra
 ! switches svis/tdrg/topt are not declared by the reference's own shared_mod.f95
-! (SURVEY F2); this host does not reference them (= 0).
+! (SURVEY F2), so by default this host does not reference them (= 0).  With a shared_mod.f95
+! that does declare them, compile with `-cpp -DBEOM_FORK_SWITCHES` (build_host.py does this
+! by itself) and they are honoured: biharmonic viscosity, top drag, surface topography.
+#ifdef BEOM_FORK_SWITCHES
+#define FORK_SVIS svis
+#define FORK_TDRG tdrg
+#define FORK_TOPT topt
+#else
+#define FORK_SVIS 0._rw
+#define FORK_TDRG 0._rw
+#define FORK_TOPT 0._rw
+#endif
 module private_mod
   use shared_mod
   use iso_c_binding
@@ -193,6 +204,14 @@ subroutine check_options()                                       ! check_consist
     call fail( -1, 'linear bottom drag coefficient bdrg has units of m s**(-1) and should be within: ' // &
                    '0 <= bdrg < 5x10**(-3) x u_max.' )
   end if
+#ifdef BEOM_FORK_SWITCHES
+  if ( (tdrg < 0._rw .or. tdrg > 15.e-3_rw) .and. qdrg > 0.5_rw ) then                    ! :1043-1051
+    call fail( -1, 'quadratic top drag coefficient tdrg should be within: 0 <= tdrg < 5x10**(-3).' )
+  else if ( tdrg < 0._rw .or. tdrg > 5.e-2_rw ) then
+    call fail( -1, 'linear top drag coefficient tdrg has units of m s**(-1) and should be within: ' // &
+                   '0 <= tdrg < 5x10**(-3) x u_max.' )
+  end if
+#endif
   if ( rgld > 0.5_rw ) call fail( -5, 'rgld = 1 (rigid lid) is not available on the MI355X path.' )
   if ( nlay > beom_max_layers ) call fail( -3, 'nlay exceeds BEOM_MAX_LAYERS of libbeom_hip.' )
 end subroutine check_options
@@ -239,10 +258,16 @@ end subroutine put_record_r4
 
 subroutine load_depth(h_2d)                                      ! keyw 'h_bo' (:827-839)
   real(rw), intent(inout) :: h_2d(-1:, -1:)
-  real(r4), allocatable   :: a(:)
+  real(r4), allocatable   :: a(:), top(:)
   if ( .not. input_exists('h_bo') ) return
   allocate( a((lm+2) * (mm+2)) )
   call get_input_r4( 'h_bo', a )
+  if ( FORK_TOPT > 0.5_rw ) then                                 ! surface topography, subtracted in real*4 (:809-832)
+    allocate( top((lm+2) * (mm+2)) )
+    call get_input_r4( 'h_to', top )
+    a = a - top
+    deallocate( top )
+  end if
   h_2d = 0._rw
   h_2d(0:lm+1, 0:mm+1) = real( reshape(a, (/ lm+2, mm+2 /)), rw )
   where ( h_2d < hdry ) h_2d = 0._rw
@@ -690,8 +715,10 @@ subroutine write_parameter_echo()
   write(unum, *) 'dt3d           = ',  dt3d,            ';'
   write(unum, *) 'bvis           = ',  bvis,            ';'
   write(unum, *) 'dvis           = ',  dvis,            ';'
+  zero = FORK_SVIS
   write(unum, *) 'svis           = ',  zero,            ';'
   write(unum, *) 'bdrg           = ',  bdrg,            ';'
+  zero = FORK_TDRG
   write(unum, *) 'tdrg           = ',  zero,            ';'
   write(unum, *) 'tole           = ',  tole,            ';'
   write(unum, *) 'nsal           = ',  nsal,            ';'
@@ -712,6 +739,7 @@ subroutine write_parameter_echo()
   write(unum, *) 'diag           = ',  diag,            ';'
   write(unum, *) 'rgld           = ',  rgld,            ';'
   write(unum, *) 'mcbc           = ',  mcbc,            ';'
+  zero = FORK_TOPT
   write(unum, *) 'topt           = ',  zero,            ';'
   write(unum, *) 'idir           = ', '''', trim(idir), '''', ';'
   write(unum, *) 'desc           = ', '''', trim(desc), '''', ';'
@@ -939,8 +967,8 @@ subroutine gpu_start()
   prm%dense_hint = 1;  prm%slab_row0 = 0;  prm%slab_mm = 0
   prm%dl = dl;  prm%dt = dt;  prm%grav = grav;  prm%rho0 = rho0
   prm%beta = beta;  prm%epsi = epsi;  prm%gamm = gamm;  prm%del1 = del1;  prm%del2 = del2
-  prm%hmin = hmin;  prm%hsal = hsal;  prm%bvis = bvis;  prm%dvis = dvis;  prm%svis = 0._rw
-  prm%bdrg = bdrg;  prm%tdrg = 0._rw;  prm%qdrg = qdrg;  prm%hsbl = hsbl;  prm%hbbl = hbbl
+  prm%hmin = hmin;  prm%hsal = hsal;  prm%bvis = bvis;  prm%dvis = dvis;  prm%svis = FORK_SVIS
+  prm%bdrg = bdrg;  prm%tdrg = FORK_TDRG;  prm%qdrg = qdrg;  prm%hsbl = hsbl;  prm%hbbl = hbbl
   prm%g_fb = g_fb;  prm%uadv = uadv;  prm%ocrp = ocrp;  prm%rgld = rgld;  prm%mcbc = mcbc
   prm%invf = invf;  prm%w_ti = w_ti(1)
   prm%rhon = 0._rw

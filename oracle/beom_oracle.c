@@ -33,6 +33,8 @@ typedef struct oracle_state {
     /* nudged open-boundary segments, Fortran segm(nseg, 18) (private_mod.f95:1060-1240); may be NULL */
     const int32_t *segm;
     int64_t nseg;
+    /* biharmonic viscosity work arrays (0:ndeg, nlay), needed when svis > 0 (private_mod.f95:40-43) */
+    double *delu, *delv, *uu4, *vv4;
 } oracle_state;
 
 #define N1 ((size_t)P->ndeg + 1)
@@ -210,6 +212,44 @@ void oracle_update_viscosity(const beom_params *P, oracle_state *S, int ilay) {
                  + (d_cc - d_bo) * (d_cc - d_bo);                            /* :2492-2500 */
         L2(S->v_cc, ipnt, ilay) = sqrt(b) * P->dvis * dl * dl + P->bvis;     /* :2501-2502 */
     }
+    if (!(P->svis > 0.0)) return;
+    /* biharmonic viscosity, thickness-weighted grad^4(u,v) (:2508-2599) */
+#pragma omp parallel for schedule(static)
+    for (int ipnt = 1; ipnt <= ndeg; ++ipnt) {                               /* :2508-2550 */
+        const int c1 = NEIG(1, ipnt), c3 = NEIG(3, ipnt), c5 = NEIG(5, ipnt), c7 = NEIG(7, ipnt);
+        double du = 0.0, dv = 0.0;
+        if (S->mk_u[ipnt] > 0.5) {
+            du = du + 1.0 / (dl * dl) * (S->mk_u[c1] * L2(S->u, c1, ilay) + S->mk_u[c3] * L2(S->u, c3, ilay)
+                                         + S->mk_u[c5] * L2(S->u, c5, ilay) + S->mk_u[c7] * L2(S->u, c7, ilay));
+            du = du - 1.0 / (dl * dl) * (S->mk_u[c1] + S->mk_u[c3] + S->mk_u[c5] + S->mk_u[c7]) * L2(S->u, ipnt, ilay);
+        }
+        if (S->mk_v[ipnt] > 0.5) {
+            dv = dv + 1.0 / (dl * dl) * (S->mk_v[c1] * L2(S->v, c1, ilay) + S->mk_v[c3] * L2(S->v, c3, ilay)
+                                         + S->mk_v[c5] * L2(S->v, c5, ilay) + S->mk_v[c7] * L2(S->v, c7, ilay));
+            dv = dv - 1.0 / (dl * dl) * (S->mk_v[c1] + S->mk_v[c3] + S->mk_v[c5] + S->mk_v[c7]) * L2(S->v, ipnt, ilay);
+        }
+        L2(S->delu, ipnt, ilay) = du;
+        L2(S->delv, ipnt, ilay) = dv;
+    }
+#pragma omp parallel for schedule(static)
+    for (int ipnt = 1; ipnt <= ndeg; ++ipnt) {                               /* :2557-2598 */
+        const int c1 = NEIG(1, ipnt), c3 = NEIG(3, ipnt), c5 = NEIG(5, ipnt), c6 = NEIG(6, ipnt), c7 = NEIG(7, ipnt);
+        const double h = L2(S->hlay, ipnt, ilay);
+        /* :2565 `real( ... )` has no kind argument: the sum is rounded to DEFAULT (single) real */
+        const double hh_q = (double)(float)(h + S->mk_n[c5] * L2(S->hlay, c5, ilay) + S->mk_n[c6] * L2(S->hlay, c6, ilay)
+                                            + S->mk_n[c7] * L2(S->hlay, c7, ilay))
+                            / (1.0 + S->mk_n[c5] + S->mk_n[c6] + S->mk_n[c7]);
+        double uu = 0.0, vv = 0.0;
+        uu = uu - 1.0 / dl * h * L2(S->delu, ipnt, ilay) + 1.0 / dl * h * L2(S->delv, ipnt, ilay);
+        vv = vv + 1.0 / dl * hh_q * L2(S->delu, ipnt, ilay) + 1.0 / dl * hh_q * L2(S->delv, ipnt, ilay);
+        if (S->subc[ipnt] <= P->lm - 1) uu = uu + 1.0 / dl * h * L2(S->delu, c1, ilay);
+        if (S->subc[ipnt + N1] <= P->mm - 1) uu = uu - 1.0 / dl * h * L2(S->delv, c3, ilay);
+        if (S->subc[ipnt] > 1) vv = vv - 1.0 / dl * hh_q * L2(S->delv, c5, ilay);
+        if (S->subc[ipnt + N1] > 1) vv = vv - 1.0 / dl * hh_q * L2(S->delu, c7, ilay);
+        if (S->mk_u[ipnt] * S->mk_v[ipnt] < 0.5) vv = 0.0;
+        L2(S->uu4, ipnt, ilay) = uu;
+        L2(S->vv4, ipnt, ilay) = vv;
+    }
 }
 
 /* ---- update_u, private_mod.f95:1422-1503 ---------------------------------------- */
@@ -244,6 +284,11 @@ void oracle_update_u(const beom_params *P, oracle_state *S, int ilay,
                        + P->del2 * H3(S->dmdx, 3, ipnt, ilay)
                        + P->gamm * H3(S->dmdx, 2, ipnt, ilay)
                        + P->epsi * H3(S->dmdx, 1, ipnt, ilay)) * gene;       /* :1456-1469 */
+        if (P->svis > 0.0)                                                   /* :1471-1473 */
+            /* `real( ... )` without kind at :1472: single-precision rounding of the difference (u only) */
+            rhsi = rhsi - P->svis * i_dl * (double)(float)(L2(S->uu4, ipnt, ilay) - L2(S->uu4, c5, ilay)
+                                                           + L2(S->vv4, c3, ilay) - L2(S->vv4, ipnt, ilay)) * i__h;
+        else
         rhsi = rhsi + (L2(S->v_cc, ipnt, ilay) * S->dive[ipnt]
                        - L2(S->v_cc, c5, ilay) * S->dive[c5]) * i_dl
                     - (L2(S->v_ll, c3, ilay) * S->rvor[c3]
@@ -292,6 +337,10 @@ void oracle_update_v(const beom_params *P, oracle_state *S, int ilay,
                        + P->del2 * H3(S->dmdy, 3, ipnt, ilay)
                        + P->gamm * H3(S->dmdy, 2, ipnt, ilay)
                        + P->epsi * H3(S->dmdy, 1, ipnt, ilay)) * gene;       /* :1541-1554 */
+        if (P->svis > 0.0)                                                   /* :1555-1557 */
+            rhsi = rhsi - P->svis * i_dl * (L2(S->vv4, c1, ilay) - L2(S->vv4, ipnt, ilay)
+                                            - L2(S->uu4, ipnt, ilay) + L2(S->uu4, c7, ilay)) * i__h;
+        else
         rhsi = rhsi + (L2(S->v_cc, ipnt, ilay) * S->dive[ipnt]
                        - L2(S->v_cc, c7, ilay) * S->dive[c7]) * i_dl
                     + (L2(S->v_ll, c1, ilay) * S->rvor[c1]
@@ -483,7 +532,8 @@ static void oracle_one_step(const beom_params *P, oracle_state *S, int tstp, int
 /* ---- integrate_time, private_mod.f95:1853-1912, for steps tstp_first.. ---------- */
 int oracle_step(const beom_params *P, oracle_state *S, int tstp_first, int nsteps,
                 double tres, double dtd8, double dt_r, double rsta, int n_3d) {
-    if (P->svis > 0 || P->rgld > 0.5) return -1;
+    if (P->rgld > 0.5) return -1;
+    if (P->svis > 0 && !S->uu4) return -1;
     if (P->flag_nudging && P->mcbc < 0.5 && !S->segm) return -2;
     for (int tstp = tstp_first; tstp < tstp_first + nsteps; ++tstp) {
         const double ctim = tres + dtd8 * (double)tstp;                      /* :1862,1887 */

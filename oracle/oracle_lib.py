@@ -23,7 +23,8 @@ _SCR_L = tuple(k + "_l" for k in SCRATCH_NAMES)
 class OracleState(C.Structure):
     _fields_ = ([(k, C.c_void_p) for k in _STATIC] + [(k, C.c_void_p) for k in STATE_NAMES]
                 + [(k, C.c_void_p) for k in SCRATCH_NAMES] + [(k, C.c_void_p) for k in _SCR_L]
-                + [("segm", C.c_void_p), ("nseg", C.c_int64)])
+                + [("segm", C.c_void_p), ("nseg", C.c_int64)]
+                + [(k, C.c_void_p) for k in ("delu", "delv", "uu4", "vv4")])
 
 
 def build():
@@ -94,12 +95,15 @@ class Oracle:
         self.st = OracleState()
         self.segm = np.ascontiguousarray(f.segm, dtype=np.int32) if getattr(f, "segm", None) is not None else None
         for k, _ in OracleState._fields_:
-            if k in ("segm", "nseg"):
+            if k in ("segm", "nseg", "delu", "delv", "uu4", "vv4"):
                 continue
             arr = self.a[k]
             present = arr is not None and (k not in ("hdot", "tide", "bodf") or f.has.get(k, True))
             setattr(self.st, k, arr.ctypes.data if present else None)
 
+        self.biharm = {k: np.zeros((f.p.nlay, n1)) for k in ("delu", "delv", "uu4", "vv4")}
+        for k, a in self.biharm.items():
+            setattr(self.st, k, a.ctypes.data)
         self.st.segm = self.segm.ctypes.data if self.segm is not None else None
         self.st.nseg = self.segm.shape[1] if self.segm is not None else 0
 

@@ -101,6 +101,7 @@ subroutine oracle_dump( tstp )
     write( unum ) mont, rvor, pvor, dive, d2hx, d2hy
     write( unum ) tt3d, tb3d, tu3d
     write( unum ) real(ctim, 8), real(ramp, 8), real(gene, 8)
+    if ( svis > 0._rw ) write( unum ) delu, delv, UU4, VV4
     close( unum )
   end if
 end subroutine oracle_dump

@@ -66,5 +66,8 @@ def read_step(path, nlay, ndeg):
     for k in ("tt3d", "tb3d", "tu3d"):
         d[k] = r.take("<f8", (nlay, 2, n1))
     d["ctim"], d["ramp"], d["gene"] = (float(x) for x in r.take("<f8", (3,)))
+    if r.pos < r.buf.size:                    # svis > 0: biharmonic work arrays
+        for k in ("delu", "delv", "uu4", "vv4"):
+            d[k] = r.take("<f8", (nlay, n1))
     r.done()
     return d

@@ -146,6 +146,13 @@ def case_obc():
     return p, {"h_bo": h_bo, "nudg": nudg, "init": init}
 
 
+def case_biharm():
+    """Biharmonic viscosity svis > 0 (private_mod.f95:2508-2599, 1471-1473, 1555-1557) on the
+    island basin: every land-mask combination meets the masked Laplacians."""
+    p, f = case_island(2)
+    return p.replace(svis="2.e10", dt3d="0."), f
+
+
 def _std_fb(pf):
     p, f = pf
     return p.replace(g_fb="0."), f
@@ -166,6 +173,7 @@ CASES = {
     "tide_sponge": (case_tide, "private_mod.f95"),
     "variant3d_3l": (case_3d_variant, "private_mod3d.f95"),
     "obc_mcbc0_2l": (case_obc, "private_mod.f95"),
+    "biharm_island_2l": (case_biharm, "private_mod.f95"),
 }
 
 

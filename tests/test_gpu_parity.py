@@ -165,10 +165,7 @@ def test_restart_split_equals_single_run():
 def test_unsupported_options_fail_loudly():
     g = Golden("stommel_24x16")
     f = _fields(g)
-    f.p = f.p.replace(svis="1.")
-    with pytest.raises(capi.BeomError):
-        capi.Engine(f)
-    f.p = f.p.replace(svis="0.", rgld="1.")
+    f.p = f.p.replace(rgld="1.")        # rigid lid: needs the elliptic solver the fork never finished
     with pytest.raises(capi.BeomError):
         capi.Engine(f)
 

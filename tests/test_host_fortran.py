@@ -30,8 +30,10 @@ def test_host_compiles_with_generated_shared_mod(tmp_path):
     exe = build_host.build(p, str(tmp_path / "beom_gpu"))
     assert os.path.exists(exe)
     nm = subprocess.run(["nm", "-u", exe], capture_output=True, text=True).stdout
-    for sym in ("beom_create", "beom_upload_state", "beom_step", "beom_download_state", "beom_sync"):
+    for sym in ("beom_create", "beom_upload_state", "beom_step", "beom_download_outputs", "beom_sync"):
         assert sym in nm, sym          # the time loop goes through the C-ABI
+    # (beom_download_state is only referenced when shared_mod's `diag` parameter is > 0.5: flang
+    #  folds the constant and drops the dead branch.)
 
 
 @pytest.mark.skipif(not (HAVE_FLANG and os.path.isdir(REF)), reason="needs flang and /root/reference")
