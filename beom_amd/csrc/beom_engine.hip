@@ -146,7 +146,6 @@ int beom_create(const beom_params *prm, int device, const int32_t *neig, const i
     if (!prm || !out) { set_err(errm, errm_len, "beom_create: null argument"); return -1; }
     if (prm->abi_version != BEOM_ABI_VERSION) { set_err(errm, errm_len, "beom_create: ABI version mismatch (%d vs %d)", prm->abi_version, BEOM_ABI_VERSION); return -2; }
     if (prm->nlay < 1 || prm->nlay > BEOM_MAX_LAYERS || prm->ndeg < 1 || prm->lm < 1 || prm->mm < 1) { set_err(errm, errm_len, "beom_create: bad sizes"); return -3; }
-    if (prm->svis > 0.0 && prm->slab_mm > 0) { set_err(errm, errm_len, "beom_create: svis > 0 (biharmonic viscosity) is not available on a j-slab"); return -4; }
     if (prm->rgld > 0.5) { set_err(errm, errm_len, "beom_create: rgld = 1 (rigid lid, private_mod.f95:1705-1838) is not implemented on the GPU path"); return -5; }
     if (prm->variant == 1 && prm->nlay < 3) { set_err(errm, errm_len, "beom_create: variant 1 (private_mod3d.f95) needs nlay >= 3"); return -7; }
     if (!neig || !subc || !mk_u || !mk_v || !mk_n || !mkpe || !mkpi || !fcor || !h_th || !nudg || !fnud) { set_err(errm, errm_len, "beom_create: null static array"); return -1; }

@@ -572,7 +572,7 @@ __device__ __forceinline__ double uv_core(const C &c, const DevView &d, int ilay
         rhsi = rhsi + (d.del1 * dmd4 + d.del2 * LL(io.dm2, ipnt, ilay) + d.gamm * LL(io.dm1, ipnt, ilay)
                        + d.epsi * LL(io.dm0, ipnt, ilay)) * gene;
     }
-    if (d.svis > 0.0) {   // biharmonic form (:1471-1473, :1555-1557); the u form rounds to default real
+    if (!PROD && d.svis > 0.0) {   // (the engine never stages products when svis > 0)  biharmonic form (:1471-1473, :1555-1557); the u form rounds to default real
         const double i__h = 1.0 / (hcen + 1.0 - mask);
         if (XDIR) rhsi = rhsi - d.svis * i_dl * (double)(float)(LL(d.uu4, ipnt, ilay) - LL(d.uu4, cb, ilay)
                                                                + LL(d.vv4, ca, ilay) - LL(d.vv4, ipnt, ilay)) * i__h;

@@ -153,6 +153,25 @@ def case_biharm():
     return p.replace(svis="2.e10", dt3d="0."), f
 
 
+def case_topdrag():
+    """The fork's top drag (tdrg > 0, distribute_stress :2006, :2075-2112) under a surface
+    topography file (topt = 1: h_2d = h_bo - h_to in real*4, :809-832), island basin."""
+    p, f = case_island(2)
+    lm, mm = p.lm, p.mm
+    x = np.arange(lm + 2)[:, None]; y = np.arange(mm + 2)[None, :]
+    # with topt = 1 the reference reads h_to into an unallocated buffer when it meets bodf.bin
+    # (:809-814): no body force in this case
+    f = {k: v for k, v in f.items() if k != "bodf"}
+    f["h_to"] = (40.0 * np.exp(-((x - 15.0) ** 2 + (y - 11.0) ** 2) / 30.0)).astype(np.float32)
+    return p.replace(tdrg="2.e-3", topt="1."), f
+
+
+def case_topdrag_ocrp():
+    """Top drag together with outcropping (ocrp = 1 branch of the stress fractions, :1991)."""
+    p, f = I.case_sill_exchange3d(lm=15, mm=41, nlay=2, dt_s=0.01, npts=5, sill_halfwidth=6.0)
+    return p.replace(tdrg="1.e-3"), f
+
+
 def _std_fb(pf):
     p, f = pf
     return p.replace(g_fb="0."), f
@@ -174,6 +193,8 @@ CASES = {
     "variant3d_3l": (case_3d_variant, "private_mod3d.f95"),
     "obc_mcbc0_2l": (case_obc, "private_mod.f95"),
     "biharm_island_2l": (case_biharm, "private_mod.f95"),
+    "topdrag_topo_2l": (case_topdrag, "private_mod.f95"),
+    "topdrag_sill_ocrp_2l": (case_topdrag_ocrp, "private_mod.f95"),
 }
 
 
