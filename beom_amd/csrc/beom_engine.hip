@@ -55,6 +55,7 @@ struct beom_engine {
     bool obc = false;                  // no_gradient_obc active (flag_nudging, mcbc < 0.5, segments set)
     bool fuse = true;                  // dense frames: Montgomery+Leith in one sweep (k_mont_visc)
     bool fuse_uv = true;               // dense frames: update_u + update_v in one sweep (k_uv_fused)
+    bool lean_d2h = true;              // fused pair: d2hx, d2hy re-derived from hlay in k_uv_fused, not stored by k_mont_visc
     char last_err[512] = {0};
 };
 
@@ -207,7 +208,7 @@ int beom_create(const beom_params *prm, int device, const int32_t *neig, const i
     d.has_bodf = any_nonzero(bodf, 2 * nl);
     d.has_nudg = any_nonzero(nudg, 3 * n1);
     d.has_hto = any_nonzero(h_to, n1);
-    d.keep_diag = 0;
+    d.keep_diag = 0; d.lean_d2h = 0; E->lean_d2h = true;
     d.dbg = getenv("BEOM_DBG") ? atoi(getenv("BEOM_DBG")) : 0;
     E->fuse = getenv("BEOM_NO_FUSE") == nullptr;
     E->fuse_uv = getenv("BEOM_NO_FUSE") == nullptr && getenv("BEOM_NO_FUSE_UV") == nullptr;
@@ -435,8 +436,9 @@ static void launch_uv(beom_engine *E, int ilay, double gene, double ramp, double
     if (!copy_hist) { if (XDIR) rot3(E->d.dmx); else rot3(E->d.dmy); }
 }
 // fused Montgomery + Leith sweep (dense frames); false if no instantiation for this nlay
-static bool launch_mont_visc(beom_engine *E) {
+static bool launch_mont_visc(beom_engine *E, bool uv_fused_follows) {
     const dim3 g = mont_visc_grid(E->d), b(BEOM_BLOCK);
+    E->d.lean_d2h = uv_fused_follows && E->lean_d2h && !E->d.keep_diag;
     switch (E->d.nlay) {
 #define CASE_NL(n) case n: hipLaunchKernelGGL((k_mont_visc<n>), g, b, 0, E->stream, E->d); return true;
         CASE_NL(1) CASE_NL(2) CASE_NL(3) CASE_NL(4) CASE_NL(5) CASE_NL(6) CASE_NL(8)
@@ -533,7 +535,7 @@ static void one_step(beom_engine *E, int tstp, const StepScalars &s) {
     if (T) T->begin(0);
     launch_h(E, s.gene, s.ramp, s.ctim);                           // :2181,2259
     if (T) { T->end(); T->begin(s.fused ? 5 : 1); }
-    const bool prod = s.fused && launch_mont_visc(E);              // :2187-2188, 2266-2269 in one sweep
+    const bool prod = s.fused && launch_mont_visc(E, s.fused_uv);              // :2187-2188, 2266-2269 in one sweep
     if (!prod) launch_mont(E, 0);
     if (T) T->end();
     if (!prod && (s.first3 || (E->P.dvis > 1.e-3 && s.upst) || E->P.svis > 0.0)) {     // :2188,2268
@@ -649,7 +651,7 @@ int beom_step_phase(beom_handle E, int tstp, double tres, double dtd8, double dt
         launch_h(E, s.gene, s.ramp, s.ctim, false);
         if (T) { T->end(); T->begin(5); }
         set_rows(d, 1, south ? 10 : 1, north ? M - 9 : M);
-        launch_mont_visc(E);
+        launch_mont_visc(E, true);
         if (T) { T->end(); T->begin(6); }
         set_rows(d, 1, south ? 11 : 1, north ? M - 10 : M);
         launch_uv_fused(E, u_first, true, s.gene, s.ramp, s.ctim, false);
@@ -666,7 +668,7 @@ int beom_step_phase(beom_handle E, int tstp, double tres, double dtd8, double dt
         launch_h(E, s.gene, s.ramp, s.ctim, true);
         if (T) { T->end(); T->begin(5); }
         strips(9);
-        launch_mont_visc(E);
+        launch_mont_visc(E, true);
         if (T) { T->end(); T->begin(6); }
         strips(10);
         launch_uv_fused(E, u_first, true, s.gene, s.ramp, s.ctim, true);
@@ -786,6 +788,7 @@ int beom_set_option(beom_handle E, const char *name, int value) {
     else if (!strcmp(name, "fuse_mont_visc")) E->fuse = value != 0;
     else if (!strcmp(name, "fuse_uv")) E->fuse_uv = value != 0;
     else if (!strcmp(name, "keep_diag")) E->d.keep_diag = value != 0;
+    else if (!strcmp(name, "lean_d2h")) E->lean_d2h = value != 0;
     else return -3;
     return 0;
 }

@@ -299,7 +299,7 @@ __device__ __forceinline__ void rv_dv_halo(const DevView &d, int a, int b, int i
 }
 
 template <int NL, bool INT>
-__device__ __forceinline__ void body_mont_visc(const DevView &d, int x0, int y0,
+__device__ __forceinline__ void body_mont_visc(const DevView &d, int x0, int y0, bool wr_d2h,
                                                double (*s_rv)[MV_LDY][MV_LDX], double (*s_dv)[MV_LDY][MV_LDX]) {
     const int tid = threadIdx.x;
     const int lx = tid & 63, wy = tid >> 6;              // column in tile, wave = row pair
@@ -402,8 +402,10 @@ __device__ __forceinline__ void body_mont_visc(const DevView &d, int x0, int y0,
                 if (hE < 2.0 * hs_8 || hW < 2.0 * hs_8 || h0 < 2.0 * hs_8) d2x = 0.0;
                 if (hN < 2.0 * hs_8 || hS < 2.0 * hs_8 || h0 < 2.0 * hs_8) d2y = 0.0;
             }
-            LL(d.d2hx, ipnt, ilay) = d2x;
-            LL(d.d2hy, ipnt, ilay) = d2y;
+            if (wr_d2h) {
+                LL(d.d2hx, ipnt, ilay) = d2x;
+                LL(d.d2hy, ipnt, ilay) = d2y;
+            }
             const double have = h0 + hW + ph6[q] + hS;
             LL(d.pvor, ipnt, ilay) = (fcor[q] + rv[q] * d.uadv) * mkpi * (mkn + mk5 + mk6 + mk7) / have;
             // Leith viscosity from the staged ring (same names as :2458-2470)
@@ -442,8 +444,13 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_mont_visc(DevView d) {
     // block-uniform: tile and its ring lie in 2..L-2 x 2..M-2 (global rows too) -> no wraps, masks = 1
     const bool interior = x0 - 1 >= 2 && x0 + MV_TX <= d.L - 2 && y0 - 1 >= 2 && y0 + MV_TY <= d.M - 2
                           && y0 - 1 + d.joff >= 2 && y0 + MV_TY + d.joff <= d.Mg - 2;
-    if (interior) body_mont_visc<NL, true>(d, x0, y0, s_rv, s_dv);
-    else body_mont_visc<NL, false>(d, x0, y0, s_rv, s_dv);
+    // d.lean_d2h (the fused u+v sweep follows): its interior workgroups re-derive d2hx, d2hy from
+    // hlay; only tiles that touch a non-interior tile of that sweep (same tiling) still store them
+    const bool deep = x0 - 1 - MV_TX >= 2 && x0 + 2 * MV_TX <= d.L - 2 && y0 - 1 - MV_TY >= 2 && y0 + 2 * MV_TY <= d.M - 2
+                      && y0 - 1 - MV_TY + d.joff >= 2 && y0 + 2 * MV_TY + d.joff <= d.Mg - 2;
+    const bool wr_d2h = !(d.lean_d2h && deep);
+    if (interior) body_mont_visc<NL, true>(d, x0, y0, wr_d2h, s_rv, s_dv);
+    else body_mont_visc<NL, false>(d, x0, y0, wr_d2h, s_rv, s_dv);
 }
 static inline dim3 mont_visc_grid(const DevView &d) { return dim3(TileMap(d, MV_TX, MV_TY).blocks(), 1, 1); }
 
@@ -501,8 +508,14 @@ struct UVio {
 #define UV_TY (4 * UV_Q)
 #define UV_LDX (UV_TX + 1 + 1)
 #define UV_SROWS (UV_TY + 2)
-#define UV_SLDX (UV_TX + 2 + 1)
+#define UV_SLDX (UV_TX + 2)
 typedef double UVstage[UV_SROWS][UV_SLDX];           // rows y0-1 .. y0+TY, cols x0-1 .. x0+TX
+// hlay is staged one cell wider: the thickness curvatures d2hx, d2hy (:2393-2404) at a cell and
+// at its W / S neighbour are re-evaluated from it, so interior workgroups never read (and the
+// Montgomery sweep never writes) those two arrays
+#define UV_HROWS (UV_TY + 4)
+#define UV_HLDX (UV_TX + 4)
+typedef double UVhstage[UV_HROWS][UV_HLDX];          // rows y0-2 .. y0+TY+1, cols x0-2 .. x0+TX+1
 
 struct ShGlobal {
     const DevView &d; int ipnt, cb, ca, ilay;
@@ -516,22 +529,37 @@ struct ShGlobal {
     __device__ __forceinline__ double pcd_b() const { return LL(d.pcd, cb, ilay); }
     __device__ __forceinline__ double qlr_s() const { return LL(d.qlr, ipnt, ilay); }
     __device__ __forceinline__ double qlr_a() const { return LL(d.qlr, ca, ilay); }
+    template <bool XDIR> __device__ __forceinline__ double d2h_s() const { return LL(XDIR ? d.d2hx : d.d2hy, ipnt, ilay); }
+    template <bool XDIR> __device__ __forceinline__ double d2h_b() const { return LL(XDIR ? d.d2hx : d.d2hy, cb, ilay); }
 };
 template <bool XDIR>
-struct ShLds {                                       // field order in the stage: 0 hlay 1 mont 2 pvor 3 pcd 4 qlr
-    const UVstage *s; int r, c;                      // staged position of the cell
+struct ShLds {                                       // field order in the stage: 0 mont 1 pvor 2 pcd 3 qlr
+    const UVstage *s; const double (*h)[UV_HLDX];    // h = the wider hlay stage
+    int r, c;                                        // staged position of the cell (UVstage coordinates)
+    double ocrp, hs2;                                // d.ocrp, 2*hsal (outcropping guard of d2h)
     static constexpr int RB = XDIR ? 0 : -1, CB = XDIR ? -1 : 0;   // b neighbour: W | S
     static constexpr int RA = XDIR ? 1 : 0, CA = XDIR ? 0 : 1;     // a neighbour: N | E
-    __device__ __forceinline__ double hlay_s() const { return s[0][r][c]; }
-    __device__ __forceinline__ double hlay_b() const { return s[0][r + RB][c + CB]; }
-    __device__ __forceinline__ double mont_s() const { return s[1][r][c]; }
-    __device__ __forceinline__ double mont_b() const { return s[1][r + RB][c + CB]; }
-    __device__ __forceinline__ double pvor_s() const { return s[2][r][c]; }
-    __device__ __forceinline__ double pvor_a() const { return s[2][r + RA][c + CA]; }
-    __device__ __forceinline__ double pcd_s() const { return s[3][r][c]; }
-    __device__ __forceinline__ double pcd_b() const { return s[3][r + RB][c + CB]; }
-    __device__ __forceinline__ double qlr_s() const { return s[4][r][c]; }
-    __device__ __forceinline__ double qlr_a() const { return s[4][r + RA][c + CA]; }
+    __device__ __forceinline__ double hlay_s() const { return h[r + 1][c + 1]; }
+    __device__ __forceinline__ double hlay_b() const { return h[r + 1 + RB][c + 1 + CB]; }
+    __device__ __forceinline__ double mont_s() const { return s[0][r][c]; }
+    __device__ __forceinline__ double mont_b() const { return s[0][r + RB][c + CB]; }
+    __device__ __forceinline__ double pvor_s() const { return s[1][r][c]; }
+    __device__ __forceinline__ double pvor_a() const { return s[1][r + RA][c + CA]; }
+    __device__ __forceinline__ double pcd_s() const { return s[2][r][c]; }
+    __device__ __forceinline__ double pcd_b() const { return s[2][r + RB][c + CB]; }
+    __device__ __forceinline__ double qlr_s() const { return s[3][r][c]; }
+    __device__ __forceinline__ double qlr_a() const { return s[3][r + RA][c + CA]; }
+    // d2hx | d2hy of the wet interior (all three masks are 1 there), as body_mont_visc writes it
+    __device__ __forceinline__ double d2h_at(int rr, int cc) const {
+        const double h0 = h[rr][cc];
+        const double hp = XDIR ? h[rr][cc + 1] : h[rr + 1][cc];    // E | N
+        const double hm = XDIR ? h[rr][cc - 1] : h[rr - 1][cc];    // W | S
+        double v = (hp + hm - h0 * 2.0) * 1.0 * 1.0 * 1.0;
+        if (ocrp > 0.5) { if (hp < hs2 || hm < hs2 || h0 < hs2) v = 0.0; }
+        return v;
+    }
+    template <bool X> __device__ __forceinline__ double d2h_s() const { return d2h_at(r + 1, c + 1); }
+    template <bool X> __device__ __forceinline__ double d2h_b() const { return d2h_at(r + 1 + RB, c + 1 + CB); }
 };
 
 template <bool XDIR, bool PROD, bool STORE, class C, class SH>
@@ -543,7 +571,6 @@ __device__ __forceinline__ double uv_core(const C &c, const DevView &d, int ilay
     // u: cb = W(5), ca = N(3);   v: cb = S(7), ca = E(1)
     const int cb = XDIR ? c.template nb<5>() : c.template nb<7>();
     const int ca = XDIR ? c.template nb<3>() : c.template nb<1>();
-    const double *d2h = XDIR ? d.d2hx : d.d2hy;
     constexpr int IV = XDIR ? 2 : 3;               // ix_u / ix_v
     constexpr int ID = XDIR ? 1 : 2;               // stress component of this direction
     constexpr int IO = XDIR ? 2 : 1;               // the other one (Ekman term of ufor/vfor)
@@ -609,8 +636,8 @@ __device__ __forceinline__ double uv_core(const C &c, const DevView &d, int ilay
         const double ng = d.has_nudg ? NUDG_(ipnt, IV) : 0.0;
         vold = vfor * ng + vold * (1.0 - ng);
     }
-    const double hnew = 0.5 * (vold + fabs(vold)) * (hcen - 0.16667 * LL(d2h, cb, ilay))
-                      + 0.5 * (vold - fabs(vold)) * (hcen - 0.16667 * LL(d2h, ipnt, ilay));   // rgld = 0 (:1491,1577)
+    const double hnew = 0.5 * (vold + fabs(vold)) * (hcen - 0.16667 * sh.template d2h_b<XDIR>())
+                      + 0.5 * (vold - fabs(vold)) * (hcen - 0.16667 * sh.template d2h_s<XDIR>());   // rgld = 0 (:1491,1577)
     if (STORE && do_store) {
         LL(io.vel_out, ipnt, ilay) = vold;
         LL(io.hp_out, ipnt, ilay) = hnew;
@@ -700,7 +727,8 @@ __device__ __forceinline__ double uv_first_halo(const DevView &d, int a, int b, 
 // form read global memory as the unfused sweeps do.
 template <bool FIRST_X, bool PROD, bool INT>
 __device__ __forceinline__ void body_uv_fused(const DevView &d, int x0, int y0, int ilay, double gene,
-                                              double ramp, double ctim, double (*s_h)[UV_LDX], UVstage *s_f) {
+                                              double ramp, double ctim, double (*s_h)[UV_LDX], UVstage *s_f,
+                                              double (*s_hl)[UV_HLDX]) {
     constexpr bool STAGED = INT && PROD;
     const int tid = threadIdx.x;
     const int lx = tid & 63, wy = tid >> 6;
@@ -709,13 +737,23 @@ __device__ __forceinline__ void body_uv_fused(const DevView &d, int x0, int y0, 
     //                  !FIRST_X -> rows y0 .. y0+TY,     cols x0-1 .. x0+TX-1 (own cell at [r][lx+1])
     constexpr int ROFF = FIRST_X ? 1 : 0, COFF = FIRST_X ? 0 : 1;
     if (STAGED) {
-        const double *src[5] = {d.hlay, d.mont, d.pvor, d.pcd, d.qlr};
+        const double *src[4] = {d.mont, d.pvor, d.pcd, d.qlr};
         const long long lay = d.n1 * (long long)(ilay - 1);
         for (int idx = tid; idx < UV_SROWS * (UV_TX + 2); idx += BEOM_BLOCK) {
             const int rr = idx / (UV_TX + 2), cc = idx - rr * (UV_TX + 2);
             const long long ip = (long long)(x0 - 1 + cc) + (long long)(y0 - 2 + rr) * d.L + lay;
 #pragma unroll
-            for (int f = 0; f < 5; ++f) s_f[f][rr][cc] = src[f][ip];
+            for (int f = 0; f < 4; ++f) s_f[f][rr][cc] = src[f][ip];
+            s_hl[rr + 1][cc + 1] = d.hlay[ip];
+        }
+        {   // outer ring of the hlay stage without its corners: d2hy needs the rows y0-2 and y0+TY+1,
+            // d2hx the columns x0-2 and x0+TX+1 (one load per thread, same round trip as the loop above)
+            int rr = -1, cc = -1;
+            if (tid < UV_TX + 2) { rr = 0; cc = 1 + tid; }
+            else if (tid < 2 * (UV_TX + 2)) { rr = UV_HROWS - 1; cc = 1 + tid - (UV_TX + 2); }
+            else if (tid < 2 * (UV_TX + 2) + UV_SROWS) { rr = 1 + tid - 2 * (UV_TX + 2); cc = 0; }
+            else if (tid < 2 * (UV_TX + 2) + 2 * UV_SROWS) { rr = 1 + tid - 2 * (UV_TX + 2) - UV_SROWS; cc = UV_HLDX - 1; }
+            if (rr >= 0) s_hl[rr][cc] = d.hlay[(long long)(x0 - 2 + cc) + (long long)(y0 - 3 + rr) * d.L + lay];
         }
         __syncthreads();
     }
@@ -730,7 +768,7 @@ __device__ __forceinline__ void body_uv_fused(const DevView &d, int x0, int y0, 
         double hnew = 0.0;
         if (ok[q]) {
             if (STAGED) {
-                const ShLds<FIRST_X> sh{s_f, r + 1, lx + 1};
+                const ShLds<FIRST_X> sh{s_f, s_hl, r + 1, lx + 1, d.ocrp, 2.0 * d.hsal};
                 hnew = uv_first_eval<FIRST_X, PROD, true, INT>(d, c[q], ilay, gene, ramp, ctim, sh, wr[q]);
             } else {
                 const int cb = FIRST_X ? c[q].template nb<5>() : c[q].template nb<7>();
@@ -761,7 +799,7 @@ __device__ __forceinline__ void body_uv_fused(const DevView &d, int x0, int y0, 
             else if (STAGED) {
                 CellDenseT<INT> h;
                 h.set_cell(d, a, b);
-                const ShLds<FIRST_X> sh{s_f, b - (y0 - 1), a - (x0 - 1)};
+                const ShLds<FIRST_X> sh{s_f, s_hl, b - (y0 - 1), a - (x0 - 1), d.ocrp, 2.0 * d.hsal};
                 hv = uv_first_eval<FIRST_X, PROD, false, INT>(d, h, ilay, gene, ramp, ctim, sh);
             } else {
                 hv = uv_first_halo<FIRST_X, PROD>(d, a, b, ilay, gene, ramp, ctim);
@@ -788,7 +826,7 @@ __device__ __forceinline__ void body_uv_fused(const DevView &d, int x0, int y0, 
             q0 = s_h[r][lx + 1]; qb = s_h[r][lx]; qa = s_h[r + 1][lx + 1]; qd = s_h[r + 1][lx];
         }
         if (STAGED) {
-            const ShLds<!FIRST_X> sh{s_f, r + 1, lx + 1};
+            const ShLds<!FIRST_X> sh{s_f, s_hl, r + 1, lx + 1, d.ocrp, 2.0 * d.hsal};
             uv_core<!FIRST_X, PROD, true>(c[q], d, ilay, gene, ramp, ctim, 0, io, q0, qb, qa, qd, sh);
         } else {
             const int cb = !FIRST_X ? c[q].template nb<5>() : c[q].template nb<7>();
@@ -802,7 +840,8 @@ __device__ __forceinline__ void body_uv_fused(const DevView &d, int x0, int y0, 
 template <bool FIRST_X, bool PROD>
 __global__ __launch_bounds__(BEOM_BLOCK) void k_uv_fused(DevView d, double gene, double ramp, double ctim) {
     __shared__ double s_h[UV_TY + 1][UV_LDX];
-    __shared__ UVstage s_f[PROD ? 5 : 1];
+    __shared__ UVstage s_f[PROD ? 4 : 1];
+    __shared__ double s_hl[PROD ? UV_HROWS : 1][UV_HLDX];
     const TileMap tm(d, UV_TX, UV_TY);
     int ty, ch;
     if (!tm.locate(blockIdx.x, ty, ch)) return;
@@ -810,8 +849,8 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_uv_fused(DevView d, double gene,
     const int ilay = blockIdx.y + 1;
     const bool interior = x0 - 1 >= 2 && x0 + UV_TX <= d.L - 2 && y0 - 1 >= 2 && y0 + UV_TY <= d.M - 2
                           && y0 - 1 + d.joff >= 2 && y0 + UV_TY + d.joff <= d.Mg - 2;
-    if (interior) body_uv_fused<FIRST_X, PROD, true>(d, x0, y0, ilay, gene, ramp, ctim, s_h, s_f);
-    else body_uv_fused<FIRST_X, PROD, false>(d, x0, y0, ilay, gene, ramp, ctim, s_h, s_f);
+    if (interior) body_uv_fused<FIRST_X, PROD, true>(d, x0, y0, ilay, gene, ramp, ctim, s_h, s_f, s_hl);
+    else body_uv_fused<FIRST_X, PROD, false>(d, x0, y0, ilay, gene, ramp, ctim, s_h, s_f, s_hl);
 }
 static inline dim3 uv_fused_grid(const DevView &d) {
     return dim3(TileMap(d, UV_TX, UV_TY).blocks(), (unsigned)d.nlay, 1);
