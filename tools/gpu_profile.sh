@@ -13,6 +13,6 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch 
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py $ARGS > $OUT/bench_write.log 2>&1
 python3 $R/tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write > $OUT/traffic.json
 cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
-tail -1 $OUT/bench_stats.log > $OUT/bench_under_rocprof.json
+grep "^{\"metric\"" $OUT/bench_stats.log | tail -1 > $OUT/bench_under_rocprof.json
 rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/stats
 cat $OUT/traffic.json | head -40
