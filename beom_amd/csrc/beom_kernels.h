@@ -271,36 +271,37 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_update_mont_all(DevView d) {
 #define MV_LDX (MV_TX + 2 + 1)          // +1 pad column
 #define MV_LDY (MV_TY + 2)
 
+// u, v around a cell: loads and arithmetic kept apart so that a thread can issue the loads of all
+// its cells (and of its ring cell) before the first use — one memory round trip per layer
 template <bool INT>
-__device__ __forceinline__ void rv_dv_at(const DevView &d, const CellDenseT<INT> &c, int ilay,
-                                         double &rv, double &dv, double &u_le, double &u_ri,
-                                         double &v_bo, double &v_to) {
+__device__ __forceinline__ void uv6_load(const DevView &d, const CellDenseT<INT> &c, int ilay, double (&w)[6]) {
     const int ipnt = c.ipnt;
     const int c1 = c.template nb<1>(), c3 = c.template nb<3>(), c5 = c.template nb<5>(), c7 = c.template nb<7>();
-    u_le = LL(d.u, ipnt, ilay); u_ri = LL(d.u, c1, ilay);
-    v_bo = LL(d.v, ipnt, ilay); v_to = LL(d.v, c3, ilay);
-    rv = (v_bo - LL(d.v, c5, ilay) - u_le + LL(d.u, c7, ilay)) * d.i_dl * c.mkpe();
-    dv = (u_ri - u_le + v_to - v_bo) * d.i_dl;
+    w[0] = LL(d.u, ipnt, ilay); w[1] = LL(d.u, c1, ilay);
+    w[2] = LL(d.v, ipnt, ilay); w[3] = LL(d.v, c3, ilay);
+    w[4] = LL(d.v, c5, ilay);   w[5] = LL(d.u, c7, ilay);
 }
-
-// rvor/dive of the (possibly wrapped / out-of-frame) local target cell (a, b)
 template <bool INT>
-__device__ __forceinline__ void rv_dv_halo(const DevView &d, int a, int b, int ilay, double &rv, double &dv) {
-    rv = 0.0; dv = 0.0;                      // sentinel: rvor(0) = dive(0) = 0 (:273,275)
+__device__ __forceinline__ void rv_dv_calc(const DevView &d, const CellDenseT<INT> &c, const double (&w)[6],
+                                           double &rv, double &dv) {
+    rv = (w[2] - w[4] - w[0] + w[5]) * d.i_dl * c.mkpe();        // (v_bo - v(W) - u_le + u(S))
+    dv = (w[1] - w[0] + w[3] - w[2]) * d.i_dl;                   // (u_ri - u_le + v_to - v_bo)
+}
+// local target (a, b) as a NEIGHBOUR lookup resolves it: wraps applied, false = out of the frame (index 0)
+template <bool INT>
+__device__ __forceinline__ bool halo_target(const DevView &d, int &a, int &b) {
     if (!INT) {
         if (d.xper) { if (a == 0) a = d.L - 1; else if (a == d.L) a = 1; }
         if (d.yper && !d.slab) { if (b == 0) b = d.M - 1; else if (b == d.M) b = 1; }
-        if (a < 1 || a > d.L || b < 1 || b > d.M) return;
+        if (a < 1 || a > d.L || b < 1 || b > d.M) return false;
     }
-    CellDenseT<INT> h;
-    h.set_cell(d, a, b);
-    double t0, t1, t2, t3;
-    rv_dv_at<INT>(d, h, ilay, rv, dv, t0, t1, t2, t3);
+    return true;
 }
 
 template <int NL, bool INT>
 __device__ __forceinline__ void body_mont_visc(const DevView &d, int x0, int y0, bool wr_d2h,
-                                               double (*s_rv)[MV_LDY][MV_LDX], double (*s_dv)[MV_LDY][MV_LDX]) {
+                                               double (*s_rv)[MV_LDY][MV_LDX], double (*s_dv)[MV_LDY][MV_LDX],
+                                               double (*s_hh)[MV_LDY][MV_LDX]) {
     const int tid = threadIdx.x;
     const int lx = tid & 63, wy = tid >> 6;              // column in tile, wave = row pair
     const int i = x0 + lx;
@@ -308,8 +309,12 @@ __device__ __forceinline__ void body_mont_visc(const DevView &d, int x0, int y0,
     // own cells: rows y0+wy (+4 per extra cell)
     CellDenseT<INT> c[MV_Q];
     bool ok[MV_Q], wr[MV_Q];
-    double hcol[MV_Q], fcor[MV_Q], h_th[MV_Q], h_to[MV_Q];
+    double hcol[MV_Q], fcor[MV_Q], h_th[MV_Q], h_to[MV_Q], hown[NL][MV_Q];
     int n1[MV_Q], n3[MV_Q], n5[MV_Q], n6[MV_Q], n7[MV_Q];
+    // The staged entry at a geometric position is what a NEIGHBOUR lookup of that target returns.
+    // Under periodic wraps the orphan column i = L / row j = M are wrap targets
+    // (private_mod.f95:619-620,647-648): they must hold the wrapped cell's values (widx).
+    int widx[MV_Q];                                      // -1: the cell's own values are staged
 #pragma unroll
     for (int q = 0; q < MV_Q; ++q) {
         const int j = y0 + wy + 4 * q;
@@ -322,53 +327,73 @@ __device__ __forceinline__ void body_mont_visc(const DevView &d, int x0, int y0,
         h_to[q] = d.has_hto ? d.h_to[c[q].ipnt] : 0.0;
         hcol[q] = 0.0;
 #pragma unroll
-        for (int l = 0; l < NL; ++l) hcol[q] = hcol[q] + LL(d.hlay, c[q].ipnt, l + 1);
+        for (int l = 0; l < NL; ++l) { hown[l][q] = LL(d.hlay, c[q].ipnt, l + 1); hcol[q] = hcol[q] + hown[l][q]; }
+        widx[q] = -1;
+        if (!INT) {
+            if (!ok[q]) widx[q] = 0;                   // beyond the frame: lookups give the sentinel
+            else if ((d.xper && i == d.L) || (d.yper && !d.slab && j == d.M)) {
+                int a = i, b = j;
+                widx[q] = halo_target<INT>(d, a, b) ? a + (b - 1) * d.L : 0;
+            }
+        }
     }
     // halo cell of this thread: ring of the (MV_TX+2) x (MV_TY+2) region
-    int ha = 0, hb = 0, hr = -1, hc = -1;
+    int hr = -1, hc = -1;
     if (tid < MV_TX + 2) { hr = 0; hc = tid; }
     else if (tid < 2 * (MV_TX + 2)) { hr = MV_TY + 1; hc = tid - (MV_TX + 2); }
     else if (tid < 2 * (MV_TX + 2) + MV_TY) { hr = 1 + tid - 2 * (MV_TX + 2); hc = 0; }
     else if (tid < 2 * (MV_TX + 2) + 2 * MV_TY) { hr = 1 + tid - 2 * (MV_TX + 2) - MV_TY; hc = MV_TX + 1; }
-    if (hr >= 0) { ha = x0 - 1 + hc; hb = y0 - 1 + hr; }
+    CellDenseT<INT> hcell;
+    int hidx = 0;                                        // packed index of the ring target, 0 = sentinel
+    hcell.set_cell(d, 1, 1);
+    if (hr >= 0) {
+        int a = x0 - 1 + hc, b = y0 - 1 + hr;
+        if (halo_target<INT>(d, a, b)) { hcell.set_cell(d, a, b); hidx = hcell.ipnt; }
+    }
 
-    // the few re-reads of the cell's own column hit L1/L2
 #pragma unroll
     for (int l = 0; l < NL; ++l) {      // must stay unrolled: d.rhon[l] may not become a dynamic index
-
         const int ilay = l + 1, buf = l & 1;
-        double rv[MV_Q], dv[MV_Q], u_le[MV_Q], u_ri[MV_Q], v_bo[MV_Q], v_to[MV_Q];
+        // every load of this layer first ...
+        double w[MV_Q][6], wh[6], hring = 0.0;
 #pragma unroll
         for (int q = 0; q < MV_Q; ++q) {
-            rv[q] = 0.0; dv[q] = 0.0; u_le[q] = u_ri[q] = v_bo[q] = v_to[q] = 0.0;
-            if (ok[q]) rv_dv_at<INT>(d, c[q], ilay, rv[q], dv[q], u_le[q], u_ri[q], v_bo[q], v_to[q]);
-            // The staged entry at a geometric position is what a NEIGHBOUR lookup of that target
-            // returns.  Under periodic wraps the orphan column i = L / row j = M are wrap targets
-            // (private_mod.f95:619-620,647-648): they must hold the wrapped cell's values.
-            double srv = rv[q], sdv = dv[q];
-            if (!INT) {
-                const int jq = y0 + wy + 4 * q;
-                if ((d.xper && i == d.L) || (d.yper && !d.slab && jq == d.M)) rv_dv_halo<INT>(d, i, jq, ilay, srv, sdv);
+            if (INT || ok[q]) uv6_load<INT>(d, c[q], ilay, w[q]);
+            else { w[q][0] = w[q][1] = w[q][2] = w[q][3] = w[q][4] = w[q][5] = 0.0; }
+        }
+        if (hr >= 0) {
+            hring = LL(d.hlay, hidx, ilay);
+            if (hidx != 0) uv6_load<INT>(d, hcell, ilay, wh);
+        }
+        // ... then the arithmetic and the stage
+        double rv[MV_Q], dv[MV_Q];
+#pragma unroll
+        for (int q = 0; q < MV_Q; ++q) {
+            rv[q] = 0.0; dv[q] = 0.0;
+            if (INT || ok[q]) rv_dv_calc<INT>(d, c[q], w[q], rv[q], dv[q]);
+            double srv = rv[q], sdv = dv[q], shh = hown[l][q];
+            if (!INT && widx[q] >= 0) {                  // rare: orphan column/row, cells beyond the frame
+                srv = 0.0; sdv = 0.0;                    // sentinel: rvor(0) = dive(0) = 0 (:273,275)
+                shh = LL(d.hlay, widx[q], ilay);
+                if (widx[q] > 0) {
+                    int a = i, b = y0 + wy + 4 * q;
+                    halo_target<INT>(d, a, b);
+                    CellDenseT<INT> t; t.set_cell(d, a, b);
+                    double wt[6];
+                    uv6_load<INT>(d, t, ilay, wt);
+                    rv_dv_calc<INT>(d, t, wt, srv, sdv);
+                }
             }
             s_rv[buf][1 + wy + 4 * q][1 + lx] = srv;
             s_dv[buf][1 + wy + 4 * q][1 + lx] = sdv;
+            s_hh[buf][1 + wy + 4 * q][1 + lx] = shh;
         }
         if (hr >= 0) {
-            double a, b;
-            rv_dv_halo<INT>(d, ha, hb, ilay, a, b);
+            double a = 0.0, b = 0.0;
+            if (hidx != 0) rv_dv_calc<INT>(d, hcell, wh, a, b);
             s_rv[buf][hr][hc] = a;
             s_dv[buf][hr][hc] = b;
-        }
-        // The thickness loads of the second half do not depend on the staged ring: issue them
-        // BEFORE the barrier so that one memory round trip per layer serves both halves
-        // (measured: 1.64 -> 1.46 ms per launch at 4096^2 x 4).
-        double ph0[MV_Q], phE[MV_Q], phW[MV_Q], phN[MV_Q], phS[MV_Q], ph6[MV_Q];
-#pragma unroll
-        for (int q = 0; q < MV_Q; ++q) {
-            ph0[q] = LL(d.hlay, c[q].ipnt, ilay);
-            phE[q] = LL(d.hlay, n1[q], ilay); phW[q] = LL(d.hlay, n5[q], ilay);
-            phN[q] = LL(d.hlay, n3[q], ilay); phS[q] = LL(d.hlay, n7[q], ilay);
-            ph6[q] = LL(d.hlay, n6[q], ilay);
+            s_hh[buf][hr][hc] = hring;
         }
         __syncthreads();
 #pragma unroll
@@ -381,7 +406,8 @@ __device__ __forceinline__ void body_mont_visc(const DevView &d, int x0, int y0,
             const double mk1 = cc.template mk_n_nb<1>(n1[q]), mk3 = cc.template mk_n_nb<3>(n3[q]),
                          mk5 = cc.template mk_n_nb<5>(n5[q]), mk6 = cc.template mk_n_nb<6>(n6[q]),
                          mk7 = cc.template mk_n_nb<7>(n7[q]);
-            const double h0 = ph0[q];
+            const double u_le = w[q][0], u_ri = w[q][1], v_bo = w[q][2], v_to = w[q][3];
+            const double h0 = hown[l][q];
             double mpot = -0.0;
             if (d.ocrp != 0.0) {
                 mpot = h0 + d.hmin * (1.0 - mkn);
@@ -391,22 +417,24 @@ __device__ __forceinline__ void body_mont_visc(const DevView &d, int x0, int y0,
             mpot = mpot - h_to[q];
             const double i_rn = d.i_rn[l];
 #pragma unroll
-            for (int m = 0; m < l; ++m) mpot = mpot - (d.rhon[l] - d.rhon[m]) * i_rn * LL(d.hlay, ipnt, m + 1);
+            for (int m = 0; m < l; ++m) mpot = mpot - (d.rhon[l] - d.rhon[m]) * i_rn * hown[m][q];
             if (d.rgld < 0.5) mpot = hcol[q] - h_th[q] + mpot;
             LL(d.mont, ipnt, ilay) = mpot + 0.25 * d.uadv * i_gr
-                                          * (u_ri[q] * u_ri[q] + u_le[q] * u_le[q] + v_to[q] * v_to[q] + v_bo[q] * v_bo[q]);
-            const double hE = phE[q], hW = phW[q], hN = phN[q], hS = phS[q];
-            double d2x = (hE + hW - h0 * 2.0) * mk1 * mk5 * mkn;
-            double d2y = (hN + hS - h0 * 2.0) * mk3 * mk7 * mkn;
-            if (d.ocrp > 0.5) {
-                if (hE < 2.0 * hs_8 || hW < 2.0 * hs_8 || h0 < 2.0 * hs_8) d2x = 0.0;
-                if (hN < 2.0 * hs_8 || hS < 2.0 * hs_8 || h0 < 2.0 * hs_8) d2y = 0.0;
-            }
+                                          * (u_ri * u_ri + u_le * u_le + v_to * v_to + v_bo * v_bo);
+            // thickness of the neighbours from the stage (what the lookups n1, n5, n3, n7, n6 return)
+            const double hE = s_hh[buf][r][cx + 1], hW = s_hh[buf][r][cx - 1], hN = s_hh[buf][r + 1][cx],
+                         hS = s_hh[buf][r - 1][cx], h6 = s_hh[buf][r - 1][cx - 1];
             if (wr_d2h) {
+                double d2x = (hE + hW - h0 * 2.0) * mk1 * mk5 * mkn;
+                double d2y = (hN + hS - h0 * 2.0) * mk3 * mk7 * mkn;
+                if (d.ocrp > 0.5) {
+                    if (hE < 2.0 * hs_8 || hW < 2.0 * hs_8 || h0 < 2.0 * hs_8) d2x = 0.0;
+                    if (hN < 2.0 * hs_8 || hS < 2.0 * hs_8 || h0 < 2.0 * hs_8) d2y = 0.0;
+                }
                 LL(d.d2hx, ipnt, ilay) = d2x;
                 LL(d.d2hy, ipnt, ilay) = d2y;
             }
-            const double have = h0 + hW + ph6[q] + hS;
+            const double have = h0 + hW + h6 + hS;
             LL(d.pvor, ipnt, ilay) = (fcor[q] + rv[q] * d.uadv) * mkpi * (mkn + mk5 + mk6 + mk7) / have;
             // Leith viscosity from the staged ring (same names as :2458-2470)
             const double r_bl = rv[q], r_br = s_rv[buf][r][cx + 1], r_tr = s_rv[buf][r + 1][cx + 1],
@@ -437,6 +465,7 @@ template <int NL>
 __global__ __launch_bounds__(BEOM_BLOCK) void k_mont_visc(DevView d) {
     __shared__ double s_rv[2][MV_LDY][MV_LDX];
     __shared__ double s_dv[2][MV_LDY][MV_LDX];
+    __shared__ double s_hh[2][MV_LDY][MV_LDX];               // hlay of tile + ring
     const TileMap tm(d, MV_TX, MV_TY);
     int ty, ch;
     if (!tm.locate(blockIdx.x, ty, ch)) return;               // whole block: no barrier is skipped by part of it
@@ -449,8 +478,8 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_mont_visc(DevView d) {
     const bool deep = x0 - 1 - MV_TX >= 2 && x0 + 2 * MV_TX <= d.L - 2 && y0 - 1 - MV_TY >= 2 && y0 + 2 * MV_TY <= d.M - 2
                       && y0 - 1 - MV_TY + d.joff >= 2 && y0 + 2 * MV_TY + d.joff <= d.Mg - 2;
     const bool wr_d2h = !(d.lean_d2h && deep);
-    if (interior) body_mont_visc<NL, true>(d, x0, y0, wr_d2h, s_rv, s_dv);
-    else body_mont_visc<NL, false>(d, x0, y0, wr_d2h, s_rv, s_dv);
+    if (interior) body_mont_visc<NL, true>(d, x0, y0, wr_d2h, s_rv, s_dv, s_hh);
+    else body_mont_visc<NL, false>(d, x0, y0, wr_d2h, s_rv, s_dv, s_hh);
 }
 static inline dim3 mont_visc_grid(const DevView &d) { return dim3(TileMap(d, MV_TX, MV_TY).blocks(), 1, 1); }
 
