@@ -39,7 +39,6 @@ struct DevView {
     double *pcd, *qlr;
     int keep_diag;                // fused sweep also stores rvor, dive, v_cc, v_ll
     int lean_d2h;                 // fused sweep stores d2hx, d2hy only where the fused u+v sweep reads them
-    int dbg;                      // ablation switches for traffic attribution (env BEOM_DBG; 0 in production)
     // biharmonic viscosity (svis > 0, :2508-2599): Laplacians and thickness-weighted fluxes
     double *delu, *delv, *uu4, *vv4; double svis;
     // nudged open-boundary segments, Fortran segm(nseg, 18) (no_gradient_obc, :2613-2679)

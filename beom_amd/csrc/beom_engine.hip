@@ -209,7 +209,6 @@ int beom_create(const beom_params *prm, int device, const int32_t *neig, const i
     d.has_nudg = any_nonzero(nudg, 3 * n1);
     d.has_hto = any_nonzero(h_to, n1);
     d.keep_diag = 0; d.lean_d2h = 0; E->lean_d2h = true;
-    d.dbg = getenv("BEOM_DBG") ? atoi(getenv("BEOM_DBG")) : 0;
     E->fuse = getenv("BEOM_NO_FUSE") == nullptr;
     E->fuse_uv = getenv("BEOM_NO_FUSE") == nullptr && getenv("BEOM_NO_FUSE_UV") == nullptr;
     E->wind = false;

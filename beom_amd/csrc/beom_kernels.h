@@ -595,7 +595,7 @@ template <bool XDIR, bool PROD, bool STORE, class C, class SH>
 __device__ __forceinline__ double uv_core(const C &c, const DevView &d, int ilay, double gene, double ramp,
                                           double ctim, int copy_hist, const UVio &io,
                                           double q0, double qb, double qa, double qd, const SH &sh,
-                                          bool do_store = true) {
+                                          bool do_store = true, const double *pre = nullptr) {
     const int ipnt = c.ipnt;
     // u: cb = W(5), ca = N(3);   v: cb = S(7), ca = E(1)
     const int cb = XDIR ? c.template nb<5>() : c.template nb<7>();
@@ -608,7 +608,8 @@ __device__ __forceinline__ double uv_core(const C &c, const DevView &d, int ilay
     const double h_self = sh.hlay_s(), m_self = sh.mont_s(), pv0 = sh.pvor_s();
     const double hcen = XDIR ? (sh.hlay_b() + h_self) / (1.0 + mask)
                              : (h_self + sh.hlay_b()) / (1.0 + mask);
-    double vold = LL(io.vel_in, ipnt, ilay);
+    // pre (staged fused sweep): [0] this cell's velocity, [5..7] its history levels, loaded ahead of use
+    double vold = pre ? pre[0] : LL(io.vel_in, ipnt, ilay);
     const double dmd4 = (sh.mont_b() - m_self) * i_dl * d.grav * mask;
     const double pva = sh.pvor_a();
     double rhsi = dmd4 * (1.0 - gene);
@@ -625,8 +626,9 @@ __device__ __forceinline__ double uv_core(const C &c, const DevView &d, int ilay
     // gene = 0 (steps 1-3, g_fb = 0): the term is (finite)*0 = +-0 and only matters for the sign of
     // an exactly-zero rhsi; fetch the history on those (rare) lanes only.
     if (gene != 0.0 || rhsi == 0.0) {
-        rhsi = rhsi + (d.del1 * dmd4 + d.del2 * LL(io.dm2, ipnt, ilay) + d.gamm * LL(io.dm1, ipnt, ilay)
-                       + d.epsi * LL(io.dm0, ipnt, ilay)) * gene;
+        const bool p = pre && gene != 0.0;
+        rhsi = rhsi + (d.del1 * dmd4 + d.del2 * (p ? pre[7] : LL(io.dm2, ipnt, ilay)) + d.gamm * (p ? pre[6] : LL(io.dm1, ipnt, ilay))
+                       + d.epsi * (p ? pre[5] : LL(io.dm0, ipnt, ilay))) * gene;
     }
     if (!PROD && d.svis > 0.0) {   // (the engine never stages products when svis > 0)  biharmonic form (:1471-1473, :1555-1557); the u form rounds to default real
         const double i__h = 1.0 / (hcen + 1.0 - mask);
@@ -721,7 +723,8 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_update_uv(DevView d, int ilay_on
 // first update at one cell; SH = where its shared fields come from
 template <bool FIRST_X, bool PROD, bool STORE, bool INT, class SH>
 __device__ __forceinline__ double uv_first_eval(const DevView &d, const CellDenseT<INT> &c, int ilay, double gene,
-                                                double ramp, double ctim, const SH &sh, bool do_store = true) {
+                                                double ramp, double ctim, const SH &sh, bool do_store = true,
+                                                const double *pre = nullptr) {
     const int ipnt = c.ipnt;
     const int cb = FIRST_X ? c.template nb<5>() : c.template nb<7>();
     const int ca = FIRST_X ? c.template nb<3>() : c.template nb<1>();
@@ -730,6 +733,8 @@ __device__ __forceinline__ double uv_first_eval(const DevView &d, const CellDens
     double *const *dm = FIRST_X ? d.dmx : d.dmy;
     const UVio io{FIRST_X ? d.u : d.v, FIRST_X ? d.u_alt : d.v_alt, FIRST_X ? d.h_u : d.h_v,
                   dm[0], dm[1], dm[2], dm[3]};
+    if (pre) return uv_core<FIRST_X, PROD, STORE>(c, d, ilay, gene, ramp, ctim, 0, io, pre[1], pre[2], pre[3], pre[4],
+                                                  sh, do_store, pre);
     return uv_core<FIRST_X, PROD, STORE>(c, d, ilay, gene, ramp, ctim, 0, io, LL(hq, ipnt, ilay),
                                          LL(hq, cb, ilay), LL(hq, ca, ilay), LL(hq, cd, ilay), sh, do_store);
 }
@@ -750,42 +755,136 @@ __device__ __forceinline__ double uv_first_halo(const DevView &d, int a, int b, 
     return uv_first_eval<FIRST_X, PROD, false, false>(d, h, ilay, gene, ramp, ctim, sh);
 }
 
-// INT = true (tile and ring strictly inside the wet interior, the bulk of the grid) with PROD:
+// Interior workgroups of the production pair (PROD, tile and ring strictly inside the wet interior):
 // the five shared fields of tile + ring are staged in LDS once and both updates, ring cells
-// included, read them there.  Boundary workgroups (wraps, sentinel, masks) and the v_cc/v_ll
-// form read global memory as the unfused sweeps do.
+// included, read them there.  All loads of a phase are issued before the first use — the
+// compiler keeps a load next to its use and would otherwise chain ~25 memory round trips
+// per workgroup (stage loop, then every cell's velocity / transports / history one after the other).
+template <bool FIRST_X>
+__device__ __forceinline__ void uv_pre_load(const DevView &d, const CellDenseT<true> &c, int ilay, double gene,
+                                            bool with_q, double (&pre)[8]) {
+    const int ipnt = c.ipnt;
+    double *const *dm = FIRST_X ? d.dmx : d.dmy;
+    pre[0] = LL(FIRST_X ? d.u : d.v, ipnt, ilay);
+    if (with_q) {       // old transport of the OTHER component at self, b, a, d (u: W,N,NW; v: S,E,SE)
+        const double *hq = FIRST_X ? d.h_v : d.h_u;
+        const int cb = FIRST_X ? c.template nb<5>() : c.template nb<7>();
+        const int ca = FIRST_X ? c.template nb<3>() : c.template nb<1>();
+        const int cd = FIRST_X ? c.template nb<4>() : c.template nb<8>();
+        pre[1] = LL(hq, ipnt, ilay); pre[2] = LL(hq, cb, ilay); pre[3] = LL(hq, ca, ilay); pre[4] = LL(hq, cd, ilay);
+    }
+    if (gene != 0.0) { pre[5] = LL(dm[0], ipnt, ilay); pre[6] = LL(dm[1], ipnt, ilay); pre[7] = LL(dm[2], ipnt, ilay); }
+}
+
+template <bool FIRST_X>
+__device__ __forceinline__ void body_uv_fused_staged(const DevView &d, int x0, int y0, int ilay, double gene,
+                                                     double ramp, double ctim, double (*s_h)[UV_LDX], UVstage *s_f,
+                                                     double (*s_hl)[UV_HLDX]) {
+    const int tid = threadIdx.x;
+    const int lx = tid & 63, wy = tid >> 6;
+    const int i = x0 + lx;
+    constexpr int ROFF = FIRST_X ? 1 : 0, COFF = FIRST_X ? 0 : 1;      // s_h coordinates as in body_uv_fused
+    constexpr int NST = UV_SROWS * (UV_TX + 2), NIT = (NST + BEOM_BLOCK - 1) / BEOM_BLOCK;
+    const long long lay = d.n1 * (long long)(ilay - 1);
+    // ---- phase A loads: stage elements, outer hlay ring, first update of own cells and of the ring cell
+    const double *src[5] = {d.mont, d.pvor, d.pcd, d.qlr, d.hlay};
+    double fv[NIT][5];
+    int frr[NIT], fcc[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const int idx = tid + k * BEOM_BLOCK;
+        const int idc = idx < NST ? idx : tid;           // clamped: the load is harmless, the store is skipped
+        frr[k] = idc / (UV_TX + 2); fcc[k] = idc - frr[k] * (UV_TX + 2);
+        const long long ip = (long long)(x0 - 1 + fcc[k]) + (long long)(y0 - 2 + frr[k]) * d.L + lay;
+#pragma unroll
+        for (int f = 0; f < 5; ++f) fv[k][f] = src[f][ip];
+    }
+    // outer ring of the hlay stage without its corners: d2hy needs the rows y0-2 and y0+TY+1,
+    // d2hx the columns x0-2 and x0+TX+1
+    int hrr = -1, hcc = -1;
+    if (tid < UV_TX + 2) { hrr = 0; hcc = 1 + tid; }
+    else if (tid < 2 * (UV_TX + 2)) { hrr = UV_HROWS - 1; hcc = 1 + tid - (UV_TX + 2); }
+    else if (tid < 2 * (UV_TX + 2) + UV_SROWS) { hrr = 1 + tid - 2 * (UV_TX + 2); hcc = 0; }
+    else if (tid < 2 * (UV_TX + 2) + 2 * UV_SROWS) { hrr = 1 + tid - 2 * (UV_TX + 2) - UV_SROWS; hcc = UV_HLDX - 1; }
+    const double hring = d.hlay[(long long)(x0 - 2 + (hrr >= 0 ? hcc : 2)) + (long long)(y0 - 3 + (hrr >= 0 ? hrr : 2)) * d.L + lay];
+    CellDenseT<true> c[UV_Q];
+    bool wr[UV_Q];
+    double pre[UV_Q][8];
+#pragma unroll
+    for (int q = 0; q < UV_Q; ++q) {
+        const int j = y0 + wy + 4 * q;
+        wr[q] = row_selected(d, j);                  // cells outside the strips are evaluated, not stored
+        c[q].set_cell(d, i, j);
+        uv_pre_load<FIRST_X>(d, c[q], ilay, gene, true, pre[q]);
+    }
+    // ring cells of the first update: one row (65) + one column (UV_TY); other threads load their own cell again
+    int rr1 = -1, cc1 = -1;
+    if (tid <= UV_TX) { rr1 = FIRST_X ? 0 : UV_TY; cc1 = tid; }
+    else if (tid <= UV_TX + UV_TY) { rr1 = (tid - UV_TX - 1) + ROFF; cc1 = FIRST_X ? UV_TX : 0; }
+    const int ra = rr1 >= 0 ? (FIRST_X ? x0 : x0 - 1) + cc1 : i;
+    const int rb = rr1 >= 0 ? (FIRST_X ? y0 - 1 : y0) + rr1 : y0 + wy;
+    CellDenseT<true> hc;
+    hc.set_cell(d, ra, rb);
+    double preR[8];
+    uv_pre_load<FIRST_X>(d, hc, ilay, gene, true, preR);
+    // ---- stage
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        if (tid + k * BEOM_BLOCK < NST) {
+#pragma unroll
+            for (int f = 0; f < 4; ++f) s_f[f][frr[k]][fcc[k]] = fv[k][f];
+            s_hl[frr[k] + 1][fcc[k] + 1] = fv[k][4];
+        }
+    }
+    if (hrr >= 0) s_hl[hrr][hcc] = hring;
+    __syncthreads();
+    // ---- phase B loads (second update): in flight while the first update is evaluated
+    double pre2[UV_Q][8];
+#pragma unroll
+    for (int q = 0; q < UV_Q; ++q) uv_pre_load<!FIRST_X>(d, c[q], ilay, gene, false, pre2[q]);
+    // ---- first update: own cells, then the ring cell
+    const double hs2 = 2.0 * d.hsal;
+#pragma unroll
+    for (int q = 0; q < UV_Q; ++q) {
+        const int r = wy + 4 * q;
+        const ShLds<FIRST_X> sh{s_f, s_hl, r + 1, lx + 1, d.ocrp, hs2};
+        s_h[r + ROFF][lx + COFF] = uv_first_eval<FIRST_X, true, true, true>(d, c[q], ilay, gene, ramp, ctim, sh, wr[q], pre[q]);
+    }
+    if (rr1 >= 0) {
+        const ShLds<FIRST_X> sh{s_f, s_hl, rb - (y0 - 1), ra - (x0 - 1), d.ocrp, hs2};
+        s_h[rr1][cc1] = uv_first_eval<FIRST_X, true, false, true>(d, hc, ilay, gene, ramp, ctim, sh, true, preR);
+    }
+    __syncthreads();
+    // ---- second component, transport of the first from LDS
+    double *const *dm = FIRST_X ? d.dmy : d.dmx;
+    const UVio io{FIRST_X ? d.v : d.u, FIRST_X ? d.v_alt : d.u_alt, FIRST_X ? d.hv_alt : d.hu_alt,
+                  dm[0], dm[1], dm[2], dm[0]};
+#pragma unroll
+    for (int q = 0; q < UV_Q; ++q) {
+        if (!wr[q]) continue;
+        const int r = wy + 4 * q;
+        double q0, qb, qa, qd;
+        if (FIRST_X) {   // v: self, S, E, SE of h_u
+            q0 = s_h[r + 1][lx]; qb = s_h[r][lx]; qa = s_h[r + 1][lx + 1]; qd = s_h[r][lx + 1];
+        } else {         // u: self, W, N, NW of h_v
+            q0 = s_h[r][lx + 1]; qb = s_h[r][lx]; qa = s_h[r + 1][lx + 1]; qd = s_h[r + 1][lx];
+        }
+        const ShLds<!FIRST_X> sh{s_f, s_hl, r + 1, lx + 1, d.ocrp, hs2};
+        uv_core<!FIRST_X, true, true>(c[q], d, ilay, gene, ramp, ctim, 0, io, q0, qb, qa, qd, sh, true, pre2[q]);
+    }
+}
+
+// Every other workgroup — boundary tiles (wraps, sentinel, masks), and all tiles of the v_cc/v_ll
+// form (PROD = false) — reads global memory as the unfused sweeps do.
 template <bool FIRST_X, bool PROD, bool INT>
 __device__ __forceinline__ void body_uv_fused(const DevView &d, int x0, int y0, int ilay, double gene,
-                                              double ramp, double ctim, double (*s_h)[UV_LDX], UVstage *s_f,
-                                              double (*s_hl)[UV_HLDX]) {
-    constexpr bool STAGED = INT && PROD;
+                                              double ramp, double ctim, double (*s_h)[UV_LDX]) {
     const int tid = threadIdx.x;
     const int lx = tid & 63, wy = tid >> 6;
     const int i = x0 + lx;
     // s_h coordinates: FIRST_X  -> rows y0-1 .. y0+TY-1, cols x0 .. x0+TX   (own cell at [r+1][lx])
     //                  !FIRST_X -> rows y0 .. y0+TY,     cols x0-1 .. x0+TX-1 (own cell at [r][lx+1])
     constexpr int ROFF = FIRST_X ? 1 : 0, COFF = FIRST_X ? 0 : 1;
-    if (STAGED) {
-        const double *src[4] = {d.mont, d.pvor, d.pcd, d.qlr};
-        const long long lay = d.n1 * (long long)(ilay - 1);
-        for (int idx = tid; idx < UV_SROWS * (UV_TX + 2); idx += BEOM_BLOCK) {
-            const int rr = idx / (UV_TX + 2), cc = idx - rr * (UV_TX + 2);
-            const long long ip = (long long)(x0 - 1 + cc) + (long long)(y0 - 2 + rr) * d.L + lay;
-#pragma unroll
-            for (int f = 0; f < 4; ++f) s_f[f][rr][cc] = src[f][ip];
-            s_hl[rr + 1][cc + 1] = d.hlay[ip];
-        }
-        {   // outer ring of the hlay stage without its corners: d2hy needs the rows y0-2 and y0+TY+1,
-            // d2hx the columns x0-2 and x0+TX+1 (one load per thread, same round trip as the loop above)
-            int rr = -1, cc = -1;
-            if (tid < UV_TX + 2) { rr = 0; cc = 1 + tid; }
-            else if (tid < 2 * (UV_TX + 2)) { rr = UV_HROWS - 1; cc = 1 + tid - (UV_TX + 2); }
-            else if (tid < 2 * (UV_TX + 2) + UV_SROWS) { rr = 1 + tid - 2 * (UV_TX + 2); cc = 0; }
-            else if (tid < 2 * (UV_TX + 2) + 2 * UV_SROWS) { rr = 1 + tid - 2 * (UV_TX + 2) - UV_SROWS; cc = UV_HLDX - 1; }
-            if (rr >= 0) s_hl[rr][cc] = d.hlay[(long long)(x0 - 2 + cc) + (long long)(y0 - 3 + rr) * d.L + lay];
-        }
-        __syncthreads();
-    }
     CellDenseT<INT> c[UV_Q];
     bool ok[UV_Q], wr[UV_Q];
 #pragma unroll
@@ -796,18 +895,13 @@ __device__ __forceinline__ void body_uv_fused(const DevView &d, int x0, int y0, 
         c[q].set_cell(d, ok[q] ? i : 1, ok[q] ? j : 1);
         double hnew = 0.0;
         if (ok[q]) {
-            if (STAGED) {
-                const ShLds<FIRST_X> sh{s_f, s_hl, r + 1, lx + 1, d.ocrp, 2.0 * d.hsal};
-                hnew = uv_first_eval<FIRST_X, PROD, true, INT>(d, c[q], ilay, gene, ramp, ctim, sh, wr[q]);
-            } else {
-                const int cb = FIRST_X ? c[q].template nb<5>() : c[q].template nb<7>();
-                const int ca = FIRST_X ? c[q].template nb<3>() : c[q].template nb<1>();
-                const ShGlobal sh{d, c[q].ipnt, cb, ca, ilay};
-                hnew = uv_first_eval<FIRST_X, PROD, true, INT>(d, c[q], ilay, gene, ramp, ctim, sh, wr[q]);
-                if (!INT) {     // orphan column/row are wrap TARGETS: stage what a neighbour lookup returns
-                    if ((d.xper && i == d.L) || (d.yper && !d.slab && j == d.M))
-                        hnew = uv_first_halo<FIRST_X, PROD>(d, i, j, ilay, gene, ramp, ctim);
-                }
+            const int cb = FIRST_X ? c[q].template nb<5>() : c[q].template nb<7>();
+            const int ca = FIRST_X ? c[q].template nb<3>() : c[q].template nb<1>();
+            const ShGlobal sh{d, c[q].ipnt, cb, ca, ilay};
+            hnew = uv_first_eval<FIRST_X, PROD, true, INT>(d, c[q], ilay, gene, ramp, ctim, sh, wr[q]);
+            if (!INT) {     // orphan column/row are wrap TARGETS: stage what a neighbour lookup returns
+                if ((d.xper && i == d.L) || (d.yper && !d.slab && j == d.M))
+                    hnew = uv_first_halo<FIRST_X, PROD>(d, i, j, ilay, gene, ramp, ctim);
             }
         }
         s_h[r + ROFF][lx + COFF] = hnew;
@@ -823,21 +917,10 @@ __device__ __forceinline__ void body_uv_fused(const DevView &d, int x0, int y0, 
         if (rr >= 0) {
             const int a = (FIRST_X ? x0 : x0 - 1) + cc;
             const int b = (FIRST_X ? y0 - 1 : y0) + rr;
-            double hv;
-            if (d.dbg & 1) hv = 0.0;
-            else if (STAGED) {
-                CellDenseT<INT> h;
-                h.set_cell(d, a, b);
-                const ShLds<FIRST_X> sh{s_f, s_hl, b - (y0 - 1), a - (x0 - 1), d.ocrp, 2.0 * d.hsal};
-                hv = uv_first_eval<FIRST_X, PROD, false, INT>(d, h, ilay, gene, ramp, ctim, sh);
-            } else {
-                hv = uv_first_halo<FIRST_X, PROD>(d, a, b, ilay, gene, ramp, ctim);
-            }
-            s_h[rr][cc] = hv;
+            s_h[rr][cc] = uv_first_halo<FIRST_X, PROD>(d, a, b, ilay, gene, ramp, ctim);
         }
     }
     __syncthreads();
-    if (d.dbg & 2) return;
     // second component, transport of the first from LDS
     double *const *dm = FIRST_X ? d.dmy : d.dmx;
     // the second component's velocity also goes to its partner buffer: an edge pass launched
@@ -854,15 +937,10 @@ __device__ __forceinline__ void body_uv_fused(const DevView &d, int x0, int y0, 
         } else {         // u: self, W, N, NW of h_v
             q0 = s_h[r][lx + 1]; qb = s_h[r][lx]; qa = s_h[r + 1][lx + 1]; qd = s_h[r + 1][lx];
         }
-        if (STAGED) {
-            const ShLds<!FIRST_X> sh{s_f, s_hl, r + 1, lx + 1, d.ocrp, 2.0 * d.hsal};
-            uv_core<!FIRST_X, PROD, true>(c[q], d, ilay, gene, ramp, ctim, 0, io, q0, qb, qa, qd, sh);
-        } else {
-            const int cb = !FIRST_X ? c[q].template nb<5>() : c[q].template nb<7>();
-            const int ca = !FIRST_X ? c[q].template nb<3>() : c[q].template nb<1>();
-            const ShGlobal sh{d, c[q].ipnt, cb, ca, ilay};
-            uv_core<!FIRST_X, PROD, true>(c[q], d, ilay, gene, ramp, ctim, 0, io, q0, qb, qa, qd, sh);
-        }
+        const int cb = !FIRST_X ? c[q].template nb<5>() : c[q].template nb<7>();
+        const int ca = !FIRST_X ? c[q].template nb<3>() : c[q].template nb<1>();
+        const ShGlobal sh{d, c[q].ipnt, cb, ca, ilay};
+        uv_core<!FIRST_X, PROD, true>(c[q], d, ilay, gene, ramp, ctim, 0, io, q0, qb, qa, qd, sh);
     }
 }
 
@@ -878,8 +956,9 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_uv_fused(DevView d, double gene,
     const int ilay = blockIdx.y + 1;
     const bool interior = x0 - 1 >= 2 && x0 + UV_TX <= d.L - 2 && y0 - 1 >= 2 && y0 + UV_TY <= d.M - 2
                           && y0 - 1 + d.joff >= 2 && y0 + UV_TY + d.joff <= d.Mg - 2;
-    if (interior) body_uv_fused<FIRST_X, PROD, true>(d, x0, y0, ilay, gene, ramp, ctim, s_h, s_f, s_hl);
-    else body_uv_fused<FIRST_X, PROD, false>(d, x0, y0, ilay, gene, ramp, ctim, s_h, s_f, s_hl);
+    if (interior && PROD) body_uv_fused_staged<FIRST_X>(d, x0, y0, ilay, gene, ramp, ctim, s_h, s_f, s_hl);
+    else if (interior) body_uv_fused<FIRST_X, PROD, true>(d, x0, y0, ilay, gene, ramp, ctim, s_h);
+    else body_uv_fused<FIRST_X, PROD, false>(d, x0, y0, ilay, gene, ramp, ctim, s_h);
 }
 static inline dim3 uv_fused_grid(const DevView &d) {
     return dim3(TileMap(d, UV_TX, UV_TY).blocks(), (unsigned)d.nlay, 1);
