@@ -396,8 +396,9 @@ static void launch_rebuild(beom_engine *E) {
 static void launch_h(beom_engine *E, double gene, double ramp, double ctim, bool rotate = true) {
     // variant 1 couples layers inside a cell -> one thread walks nlay..1; variant 0: layer = blockIdx.y
     const int nz = (E->d.variant == 1) ? 1 : E->d.nlay;
-    if (E->d.has_nudg) LAUNCH_CTX((k_update_h<CellGather, true>), (k_update_h<CellDense, true>), nz, E->d, gene, ramp, ctim, 0);
-    else LAUNCH_CTX((k_update_h<CellGather, false>), (k_update_h<CellDense, false>), nz, E->d, gene, ramp, ctim, 0);
+    if (E->d.has_nudg && E->d.has_tide) LAUNCH_CTX((k_update_h<CellGather, 2>), (k_update_h<CellDense, 2>), nz, E->d, gene, ramp, ctim, 0);
+    else if (E->d.has_nudg) LAUNCH_CTX((k_update_h<CellGather, 1>), (k_update_h<CellDense, 1>), nz, E->d, gene, ramp, ctim, 0);
+    else LAUNCH_CTX((k_update_h<CellGather, 0>), (k_update_h<CellDense, 0>), nz, E->d, gene, ramp, ctim, 0);
     if (rotate) rot2(E->d.rs);
 }
 template <class CTX>

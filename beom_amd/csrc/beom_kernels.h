@@ -48,9 +48,11 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_rebuild_fluxes(DevView d) {
 // Layers nlay..1 are walked inside the thread (variant 1 reads hlay(ipnt,3) across layers).
 // FORCED=false compiles the nudging / tide / private_mod3d epilogue out (keeps cos() and its
 // registers away from the common unforced launch); the host picks by d.has_nudg.
-template <bool FORCED, class C>
+// FORCE: 0 = no nudging, 1 = nudging, 2 = nudging + tidal constituent (the cos path costs ~50 VGPR)
+template <int FORCE, class C>
 __device__ __forceinline__ void body_update_h(const C &c, const DevView &d, double gene, double ramp,
                                                          double ctim, int copy_hist) {
+    constexpr bool FORCED = FORCE > 0;
     const int ipnt = c.ipnt;
     const int c1 = c.template nb<1>(), c3 = c.template nb<3>();
     const double i_dl = d.i_dl;
@@ -86,7 +88,7 @@ __device__ __forceinline__ void body_update_h(const C &c, const DevView &d, doub
         double hnew = 0.0 + hold;
         if (FORCED) {
             double hfor = FNUD_(ipnt, ilay, 1);
-            if (d.has_tide) {
+            if (FORCE > 1) {
                 const double vecl = (ilay == 1) ? 1.0 : 0.0;
                 hfor = hfor + ramp * TIDE_(1, ipnt, 1) * vecl * cos(TIDE_(2, ipnt, 1) - d.w_ti * ctim);
             }
@@ -119,13 +121,13 @@ __device__ __forceinline__ void body_update_h(const C &c, const DevView &d, doub
         }
     }
 }
-template <class CTX, bool FORCED>
+template <class CTX, int FORCE>
 __global__ __launch_bounds__(BEOM_BLOCK) void k_update_h(DevView d, double gene, double ramp,
                                                          double ctim, int copy_hist) {
     CTX c;
     if (!c.init(d)) return;
-    if (c.wave_is_interior()) body_update_h<FORCED>(c.as_interior(), d, gene, ramp, ctim, copy_hist);
-    else body_update_h<FORCED>(c, d, gene, ramp, ctim, copy_hist);
+    if (c.wave_is_interior()) body_update_h<FORCE>(c.as_interior(), d, gene, ramp, ctim, copy_hist);
+    else body_update_h<FORCE>(c, d, gene, ramp, ctim, copy_hist);
 }
 
 // ---- update_mont_rvor_pvor_dive_kine, private_mod.f95:2318-2439 ---------------------
