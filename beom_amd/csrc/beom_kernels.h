@@ -757,6 +757,7 @@ __device__ __forceinline__ double uv_first_halo(const DevView &d, int a, int b, 
     return uv_first_eval<FIRST_X, PROD, false, false>(d, h, ilay, gene, ramp, ctim, sh);
 }
 
+static_assert(MV_TX == UV_TX && MV_TY == UV_TY, "lean_d2h: k_mont_visc decides per tile of k_uv_fused's tiling which curvatures to store");
 // Interior workgroups of the production pair (PROD, tile and ring strictly inside the wet interior):
 // the five shared fields of tile + ring are staged in LDS once and both updates, ring cells
 // included, read them there.  All loads of a phase are issued before the first use — the
