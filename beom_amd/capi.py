@@ -121,6 +121,20 @@ def load(path: Optional[str] = None) -> C.CDLL:
                                       C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.beom_is_dense.argtypes = [H]
     lib.beom_profile_steps.argtypes = [H, ci, ci, cd, cd, cd, cd, ci, dpp, C.POINTER(ci), cp, ci]
+    MH = C.c_void_p
+    lib.beom_multi_create.argtypes = [C.POINTER(BeomParams), ci, C.POINTER(ci), ipp, ipp] + [dpp] * 14 + [C.POINTER(MH), cp, ci]
+    lib.beom_multi_destroy.argtypes = [MH]
+    lib.beom_multi_count.argtypes = [MH]
+    lib.beom_multi_band.argtypes = [MH, ci] + [C.POINTER(ci)] * 5
+    lib.beom_multi_upload_state.argtypes = [MH] + [dpp] * 13 + [cp, ci]
+    lib.beom_multi_download_state.argtypes = [MH] + [dpp] * 13 + [cp, ci]
+    lib.beom_multi_step.argtypes = [MH, ci, ci, cd, cd, cd, cd, ci, cp, ci]
+    lib.beom_multi_sync.argtypes = [MH, cp, ci]
+    lib.beom_multi_stats.argtypes = [MH, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+    for name in ("beom_multi_create", "beom_multi_destroy", "beom_multi_count", "beom_multi_band",
+                 "beom_multi_upload_state", "beom_multi_download_state", "beom_multi_step", "beom_multi_sync",
+                 "beom_multi_stats"):
+        getattr(lib, name).restype = ci
     for name in ("beom_device_count", "beom_create", "beom_destroy", "beom_upload_state",
                  "beom_download_state", "beom_download_scratch", "beom_step", "beom_sync",
                  "beom_update_h", "beom_update_mont_rvor_pvor_dive_kine", "beom_update_viscosity",
@@ -142,7 +156,10 @@ EXPORTS = ("beom_abi_version", "beom_device_count", "beom_create", "beom_destroy
            "beom_distribute_stress", "beom_device_field", "beom_is_dense", "beom_profile_steps",
            "beom_set_stream", "beom_profile_start", "beom_profile_stop", "beom_set_option",
            "beom_step_phase", "beom_pack_rows", "beom_unpack_rows", "beom_download_outputs",
-           "beom_set_open_boundaries")
+           "beom_set_open_boundaries",
+           "beom_multi_create", "beom_multi_destroy", "beom_multi_count", "beom_multi_band",
+           "beom_multi_upload_state", "beom_multi_download_state", "beom_multi_step", "beom_multi_sync",
+           "beom_multi_stats")
 
 STATE_NAMES = ("hlay", "u", "v", "h_u", "h_v", "rs_h", "dmdx", "dmdy", "v_cc", "v_ll",
                "tt3d", "tb3d", "tu3d")
@@ -311,3 +328,74 @@ class Engine:
     def update_v(self, ilay, gene, ramp, ctim): self._check(self.lib.beom_update_v(self.h, ilay, gene, ramp, ctim))
     def rebuild_fluxes(self): self._check(self.lib.beom_rebuild_fluxes(self.h))
     def distribute_stress(self): self._check(self.lib.beom_distribute_stress(self.h))
+
+
+class MultiEngine:
+    """beom_multi_*: the whole frame on several HIP devices from ONE process (row bands with ghost
+    exchange inside the library) — what the Fortran host uses with BEOM_NGPU > 1.  `devices` may
+    name a device more than once (tests: three bands on the one GPU of the box)."""
+
+    def __init__(self, f: Fields, devices=(0,), variant: int = 0, upload: bool = True):
+        self.lib = load()
+        self.f, self.p = f, f.p
+        self.prm = make_params_struct(f.p, f, variant, 1, 0, 0)
+        self._err = C.create_string_buffer(ERRLEN + 1)
+        self.h = C.c_void_p()
+        dev = (C.c_int * len(devices))(*devices)
+        opt = lambda k: _dp(getattr(f, k)) if f.has.get(k, True) else None
+        rc = self.lib.beom_multi_create(
+            C.byref(self.prm), len(devices), dev, _ip(f.neig), _ip(f.subc),
+            _dp(f.mk_u), _dp(f.mk_v), _dp(f.mk_n), _dp(f.mkpe), _dp(f.mkpi),
+            _dp(f.fcor), _dp(f.h_th), _dp(f.h_to), _dp(f.nudg), _dp(f.fnud),
+            opt("hdot"), opt("tide"), opt("bodf"), _dp(f.taus),
+            C.byref(self.h), self._err, ERRLEN)
+        self._check(rc)
+        if upload:
+            self.upload(**{k: getattr(f, k) for k in STATE_NAMES})
+
+    _check = Engine._check
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            self.lib.beom_multi_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def count(self) -> int:
+        return self.lib.beom_multi_count(self.h)
+
+    def band(self, k: int) -> dict:
+        v = [C.c_int() for _ in range(5)]
+        self._check(self.lib.beom_multi_band(self.h, k, *[C.byref(x) for x in v]))
+        return dict(zip(("own0", "own1", "win0", "win1", "device"), (x.value for x in v)))
+
+    def upload(self, **arrays):
+        args = [_dp(arrays.get(k)) for k in STATE_NAMES]
+        self._check(self.lib.beom_multi_upload_state(self.h, *args, self._err, ERRLEN))
+
+    def download(self, names=STATE_NAMES) -> dict:
+        out = {k: np.zeros_like(getattr(self.f, k)) for k in names}
+        args = [_dp(out.get(k)) for k in STATE_NAMES]
+        self._check(self.lib.beom_multi_download_state(self.h, *args, self._err, ERRLEN))
+        return out
+
+    def step(self, tstp_first: int, nsteps: int, tres: float = 0.0, sync: bool = True):
+        p = self.p
+        self._check(self.lib.beom_multi_step(self.h, tstp_first, nsteps, tres, float(p.dtd8), float(p.dt_r),
+                                             float(p.rsta), p.n_3d, self._err, ERRLEN))
+        if sync:
+            self.sync()
+
+    def sync(self):
+        self._check(self.lib.beom_multi_sync(self.h, self._err, ERRLEN))
+
+    def stats(self) -> dict:
+        a, b = C.c_longlong(), C.c_longlong()
+        self.lib.beom_multi_stats(self.h, C.byref(a), C.byref(b))
+        return {"split": a.value, "plain": b.value}

@@ -109,6 +109,69 @@ module beom_cabi
       integer(c_int)           :: rc
     end function beom_set_open_boundaries
 
+    ! ---- one process, several GPUs: row bands inside the library (include/beom_hip.h) ----
+    function beom_multi_create(prm, ndev, devices, neig, subc, mk_u, mk_v, mk_n, mkpe, mkpi, fcor,   &
+                               h_th, h_to, nudg, fnud, hdot, tide, bodf, taus, handle,              &
+                               errm, errm_len) bind(C, name = 'beom_multi_create') result(rc)
+      import :: c_int, c_ptr, c_char, beom_params
+      type(beom_params), intent(in)  :: prm
+      integer(c_int), value          :: ndev
+      integer(c_int), intent(in)     :: devices(*)
+      type(c_ptr), value             :: neig, subc, mk_u, mk_v, mk_n, mkpe, mkpi, fcor, &
+                                        h_th, h_to, nudg, fnud, hdot, tide, bodf, taus
+      type(c_ptr), intent(out)       :: handle
+      character(kind = c_char)       :: errm(*)
+      integer(c_int), value          :: errm_len
+      integer(c_int)                 :: rc
+    end function beom_multi_create
+
+    function beom_multi_destroy(handle) bind(C, name = 'beom_multi_destroy') result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: handle
+      integer(c_int)     :: rc
+    end function beom_multi_destroy
+
+    function beom_multi_upload_state(handle, hlay, u, v, h_u, h_v, rs_h, dmdx, dmdy, v_cc,    &
+                                     v_ll, tt3d, tb3d, tu3d, errm, errm_len)                   &
+             bind(C, name = 'beom_multi_upload_state') result(rc)
+      import :: c_int, c_ptr, c_char
+      type(c_ptr), value       :: handle, hlay, u, v, h_u, h_v, rs_h, dmdx, dmdy, v_cc,  &
+                                  v_ll, tt3d, tb3d, tu3d
+      character(kind = c_char) :: errm(*)
+      integer(c_int), value    :: errm_len
+      integer(c_int)           :: rc
+    end function beom_multi_upload_state
+
+    function beom_multi_download_state(handle, hlay, u, v, h_u, h_v, rs_h, dmdx, dmdy, v_cc,  &
+                                       v_ll, tt3d, tb3d, tu3d, errm, errm_len)                 &
+             bind(C, name = 'beom_multi_download_state') result(rc)
+      import :: c_int, c_ptr, c_char
+      type(c_ptr), value       :: handle, hlay, u, v, h_u, h_v, rs_h, dmdx, dmdy, v_cc,  &
+                                  v_ll, tt3d, tb3d, tu3d
+      character(kind = c_char) :: errm(*)
+      integer(c_int), value    :: errm_len
+      integer(c_int)           :: rc
+    end function beom_multi_download_state
+
+    function beom_multi_step(handle, tstp_first, nsteps, tres, dtd8, dt_r, rsta, n_3d,        &
+                             errm, errm_len) bind(C, name = 'beom_multi_step') result(rc)
+      import :: c_int, c_ptr, c_char, c_double
+      type(c_ptr), value       :: handle
+      integer(c_int), value    :: tstp_first, nsteps, n_3d
+      real(c_double), value    :: tres, dtd8, dt_r, rsta
+      character(kind = c_char) :: errm(*)
+      integer(c_int), value    :: errm_len
+      integer(c_int)           :: rc
+    end function beom_multi_step
+
+    function beom_multi_sync(handle, errm, errm_len) bind(C, name = 'beom_multi_sync') result(rc)
+      import :: c_int, c_ptr, c_char
+      type(c_ptr), value       :: handle
+      character(kind = c_char) :: errm(*)
+      integer(c_int), value    :: errm_len
+      integer(c_int)           :: rc
+    end function beom_multi_sync
+
     function beom_is_dense(handle) bind(C, name = 'beom_is_dense') result(rc)
       import :: c_int, c_ptr
       type(c_ptr), value :: handle

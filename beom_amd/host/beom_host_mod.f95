@@ -49,6 +49,8 @@ module private_mod
   real(r8) :: tres
   logical  :: has_hdot, has_tide, has_bodf, nudging_on
   type(c_ptr) :: gpu = c_null_ptr
+  type(c_ptr) :: gpus = c_null_ptr          ! BEOM_NGPU > 1: row bands on several devices (beom_multi_*)
+  integer     :: ngpu = 1
   integer  :: out_rec = 0
   logical  :: out_ready = .false.
 
@@ -58,6 +60,10 @@ contains
 subroutine run()
   call setup_state()
   call advance()
+  if ( c_associated(gpus) ) then
+    if ( beom_multi_destroy(gpus) /= 0 ) continue
+    gpus = c_null_ptr
+  end if
   if ( c_associated(gpu) ) then
     if ( beom_destroy(gpu) /= 0 ) continue
   end if
@@ -960,6 +966,9 @@ subroutine gpu_start()
   character(kind = c_char) :: cmsg(lstr + 1)
   type(c_ptr) :: p_hdot, p_tide, p_bodf
   integer(c_int) :: rc
+  integer(c_int), allocatable :: devs(:)
+  character(len = 16) :: envv
+  integer :: ios, k
   prm%abi_version = beom_abi_ver
   prm%lm = lm;  prm%mm = mm;  prm%nlay = nlay;  prm%ndeg = ndeg;  prm%nsal = nsal
   prm%variant = 0
@@ -978,6 +987,28 @@ subroutine gpu_start()
   if ( has_tide ) p_tide = c_loc(tide)
   if ( has_bodf ) p_bodf = c_loc(bodf)
   cmsg = c_null_char
+  call get_environment_variable( 'BEOM_NGPU', envv, status = ios )
+  ngpu = 1
+  if ( ios == 0 ) read( envv, *, iostat = ios ) ngpu
+  if ( ios /= 0 .or. ngpu < 1 ) ngpu = 1
+  if ( ngpu > 1 ) then                                            ! one process, ngpu devices: bands of rows
+    allocate( devs(ngpu) )
+    do k = 1, ngpu
+      devs(k) = int(k - 1, c_int)
+    end do
+    rc = beom_multi_create( prm, int(ngpu, c_int), devs, c_loc(neig), c_loc(subc), c_loc(mk_u), c_loc(mk_v),  &
+                            c_loc(mk_n), c_loc(mkpe), c_loc(mkpi), c_loc(fcor), c_loc(h_th), c_loc(h_to),      &
+                            c_loc(nudg), c_loc(fnud), p_hdot, p_tide, p_bodf, c_loc(taus), gpus, cmsg,         &
+                            int(lstr, c_int) )
+    call gpu_check( rc, cmsg, 'beom_multi_create' )
+    rc = beom_multi_upload_state( gpus, c_loc(hlay), c_loc(u), c_loc(v), c_loc(h_u), c_loc(h_v), c_loc(rs_h), &
+                                  c_loc(dmdx), c_loc(dmdy), c_loc(v_cc), c_loc(v_ll), c_loc(tt3d),           &
+                                  c_loc(tb3d), c_loc(tu3d), cmsg, int(lstr, c_int) )
+    call gpu_check( rc, cmsg, 'beom_multi_upload_state' )
+    write(ioso, *) 'MI355X engine: ', ngpu, ' devices, row bands with ghost exchange.'
+    deallocate( devs )
+    return
+  end if
   rc = beom_create( prm, 0_c_int, c_loc(neig), c_loc(subc), c_loc(mk_u), c_loc(mk_v), c_loc(mk_n), &
                     c_loc(mkpe), c_loc(mkpi), c_loc(fcor), c_loc(h_th), c_loc(h_to), c_loc(nudg),  &
                     c_loc(fnud), p_hdot, p_tide, p_bodf, c_loc(taus), gpu, cmsg, int(lstr, c_int) )
@@ -1015,19 +1046,35 @@ subroutine advance()
   cmsg = c_null_char
 
   ! steps 1-3: plain forward-backward, never followed by an output (:1861-1875)
-  rc = beom_step( gpu, 1_c_int, 3_c_int, tres, dtd8, real(dt_r, c_double), real(rsta, c_double), &
-                  int(n_3d, c_int), cmsg, int(lstr, c_int) )
+  if ( ngpu > 1 ) then
+    rc = beom_multi_step( gpus, 1_c_int, 3_c_int, tres, dtd8, real(dt_r, c_double), real(rsta, c_double), &
+                          int(n_3d, c_int), cmsg, int(lstr, c_int) )
+  else
+    rc = beom_step( gpu, 1_c_int, 3_c_int, tres, dtd8, real(dt_r, c_double), real(rsta, c_double), &
+                    int(n_3d, c_int), cmsg, int(lstr, c_int) )
+  end if
   call gpu_check( rc, cmsg, 'beom_step' )
 
   first = 4
   do while ( first <= nstp )
     last = min( ((first + notp - 1) / notp) * notp, nstp )       ! run up to the next output step
-    rc = beom_step( gpu, int(first, c_int), int(last - first + 1, c_int), tres, dtd8,            &
-                    real(dt_r, c_double), real(rsta, c_double), int(n_3d, c_int), cmsg, int(lstr, c_int) )
+    if ( ngpu > 1 ) then
+      rc = beom_multi_step( gpus, int(first, c_int), int(last - first + 1, c_int), tres, dtd8,     &
+                            real(dt_r, c_double), real(rsta, c_double), int(n_3d, c_int), cmsg, int(lstr, c_int) )
+    else
+      rc = beom_step( gpu, int(first, c_int), int(last - first + 1, c_int), tres, dtd8,            &
+                      real(dt_r, c_double), real(rsta, c_double), int(n_3d, c_int), cmsg, int(lstr, c_int) )
+    end if
     call gpu_check( rc, cmsg, 'beom_step' )
     if ( mod(last, notp) == 0 ) then
       ctim = real( tres + dtd8 * real(last, r8), rw )
-      if ( diag > 0.5_rw ) then                                  ! pvor/mont/v_cc are diagnosed on the host
+      if ( ngpu > 1 ) then                                       ! gather the owned rows of every band
+        rc = beom_multi_download_state( gpus, c_loc(hlay), c_loc(u), c_loc(v), c_null_ptr, c_null_ptr, c_null_ptr, &
+                                        c_null_ptr, c_null_ptr, c_null_ptr, c_null_ptr, c_null_ptr, c_null_ptr,  &
+                                        c_null_ptr, cmsg, int(lstr, c_int) )
+        call gpu_check( rc, cmsg, 'beom_multi_download_state' )
+        call write_outputs()
+      else if ( diag > 0.5_rw ) then                                  ! pvor/mont/v_cc are diagnosed on the host
         rc = beom_download_state( gpu, c_loc(hlay), c_loc(u), c_loc(v), c_null_ptr, c_null_ptr, c_null_ptr, &
                                   c_null_ptr, c_null_ptr, c_null_ptr, c_null_ptr, c_null_ptr, c_null_ptr,  &
                                   c_null_ptr, cmsg, int(lstr, c_int) )
@@ -1039,7 +1086,11 @@ subroutine advance()
     end if
     first = last + 1
   end do
-  rc = beom_sync( gpu, cmsg, int(lstr, c_int) )
+  if ( ngpu > 1 ) then
+    rc = beom_multi_sync( gpus, cmsg, int(lstr, c_int) )
+  else
+    rc = beom_sync( gpu, cmsg, int(lstr, c_int) )
+  end if
   call gpu_check( rc, cmsg, 'beom_sync' )
   if ( errc /= 0 ) call quit()
   errm = errm(1:lerm)

@@ -206,6 +206,49 @@ int beom_profile_steps(beom_handle h, int tstp_first, int nsteps,
                        double tres, double dtd8, double dt_r, double rsta, int n_3d,
                        double *ms, int *launches, char *errm, int errm_len);
 
+/* ---- One process, several GPUs (SURVEY §8b "Threading", §8e) ---------------------------------
+ * For hosts that stay single-process (the Fortran host under main.f95).  The whole dense frame
+ * (ndeg = (lm+1)(mm+1), not periodic in y when ndev > 1) is cut into ndev bands of rows, band k
+ * on HIP device devices[k] (the same device may be named more than once), each an ordinary slab
+ * handle with 4 ghost rows per neighbour; per time step one exchange of hlay,u,v,h_u,h_v
+ * (beom_pack_rows -> hipMemcpyPeerAsync over xGMI on the receiver's second stream ->
+ * beom_unpack_rows) overlapped with phase 1 of the next step.  Arguments as beom_create /
+ * beom_upload_state / beom_download_state / beom_step, with GLOBAL arrays; results are
+ * bit-identical to the single-device handle.  (bench.py's N-GPU path is the other form of the
+ * same scheme: one process per GPU, exchange over RCCL — beom_amd/slab.py.) */
+typedef struct beom_multi *beom_multi_handle;
+int beom_multi_create(const beom_params *prm, int ndev, const int *devices,
+                      const int32_t *neig, const int32_t *subc,
+                      const double *mk_u, const double *mk_v, const double *mk_n,
+                      const double *mkpe, const double *mkpi,
+                      const double *fcor, const double *h_th, const double *h_to,
+                      const double *nudg, const double *fnud, const double *hdot,
+                      const double *tide, const double *bodf, const double *taus,
+                      beom_multi_handle *out, char *errm, int errm_len);
+int beom_multi_destroy(beom_multi_handle h);
+int beom_multi_count(beom_multi_handle h);
+/* band k: owned global rows own0..own1, local window win0..win1 (1-based, inclusive), device */
+int beom_multi_band(beom_multi_handle h, int k, int *own0, int *own1, int *win0, int *win1, int *device);
+int beom_multi_upload_state(beom_multi_handle h,
+                            const double *hlay, const double *u, const double *v,
+                            const double *h_u, const double *h_v,
+                            const double *rs_h, const double *dmdx, const double *dmdy,
+                            const double *v_cc, const double *v_ll,
+                            const double *tt3d, const double *tb3d, const double *tu3d,
+                            char *errm, int errm_len);
+int beom_multi_download_state(beom_multi_handle h,
+                              double *hlay, double *u, double *v, double *h_u, double *h_v,
+                              double *rs_h, double *dmdx, double *dmdy,
+                              double *v_cc, double *v_ll,
+                              double *tt3d, double *tb3d, double *tu3d,
+                              char *errm, int errm_len);
+int beom_multi_step(beom_multi_handle h, int tstp_first, int nsteps,
+                    double tres, double dtd8, double dt_r, double rsta, int n_3d,
+                    char *errm, int errm_len);
+int beom_multi_sync(beom_multi_handle h, char *errm, int errm_len);
+/* how many band-steps ran in two phases (exchange overlapped) and how many in one piece */
+int beom_multi_stats(beom_multi_handle h, long long *split_band_steps, long long *plain_band_steps);
+
 #ifdef __cplusplus
 }
 #endif

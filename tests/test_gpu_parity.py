@@ -464,3 +464,58 @@ def test_device_side_output_records(name):
     eta2, _, _, _, _ = e.download_outputs(None)
     assert np.array_equal(eta2.view(np.uint32), eta.view(np.uint32))
     e.close()
+
+
+@pytest.mark.parametrize("case,nband", [("closed_tall", 3), ("sill_tall", 2), ("stommel_tall", 2), ("soliton_xper", 2)])
+def test_one_process_several_bands_match_single_handle(case, nband):
+    """beom_multi_* (the single-process multi-GPU form the Fortran host uses): bands of rows, ghost
+    exchange by peer copy on second streams, overlapped split steps — here with every band on
+    the one GPU of the box.  The gathered state must equal the single handle's bit for bit,
+    through an upload/download round trip in the middle."""
+    from beom_amd import inputs as I
+    from beom_amd.grid import read_input_data
+    p, files = {
+        "closed_tall": lambda: I.case_headline(150, 260, 3),
+        "sill_tall": lambda: I.case_sill_exchange3d(lm=133, mm=199, nlay=4, dt_s=0.01, npts=5, sill_halfwidth=20.0),
+        "stommel_tall": lambda: I.case_stommel(lm=140, mm=150, dl=50.0e3, dt_s=0.2),
+        "soliton_xper": lambda: I.case_soliton(lm=141, mm=63, dt_s=5.0),
+    }[case]()
+    f = read_input_data(p, files=files)
+    one = capi.Engine(f)
+    many = capi.MultiEngine(f, devices=[0] * nband)
+    assert many.count == nband
+    b0, b1 = many.band(0), many.band(1)
+    assert b0["own0"] == 1 and b1["own0"] == b0["own1"] + 1 and b1["win0"] == b1["own0"] - 4
+    one.step(1, 9); many.step(1, 9)
+    a, b = one.download(), many.download()
+    for k in STATE:
+        assert same(a[k], b[k]), (case, k, "after 9 steps")
+    many.upload(**b)                                   # round trip: scatter the gathered state again
+    one.step(10, 14); many.step(10, 7); many.step(17, 7)
+    a, b = one.download(), many.download()
+    for k in PROGNOSTIC:
+        assert same(a[k], b[k]), (case, k, "after 23 steps")
+    st = many.stats()
+    assert st["split"] + st["plain"] == 23 * nband
+    if case == "closed_tall":                          # unforced, fused: every step after the 3rd of a call sequence is split
+        assert st["split"] >= 15 * nband, st
+    one.close(); many.close()
+
+
+def test_multi_refuses_what_it_cannot_split():
+    from beom_amd import inputs as I
+    from beom_amd.grid import read_input_data
+    p, files = I.case_unstable_jet(lm=40, mm=60, nlay=2, dt_s=1.5)       # periodic in y
+    f = read_input_data(p, files=files)
+    with pytest.raises(capi.BeomError):
+        capi.MultiEngine(f, devices=[0, 0])
+    m = capi.MultiEngine(f, devices=[0])                                  # one band is fine
+    m.step(1, 5)
+    one = capi.Engine(f); one.step(1, 5)
+    a, b = one.download(), m.download()
+    for k in PROGNOSTIC:
+        assert same(a[k], b[k]), k
+    m.close(); one.close()
+    g = Golden("island_3l_forced")                                        # land: not a dense frame
+    with pytest.raises(capi.BeomError):
+        capi.MultiEngine(_fields(g), devices=[0, 0])

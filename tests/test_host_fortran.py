@@ -45,23 +45,30 @@ def test_drop_in_under_unchanged_reference_main_and_shared_mod(tmp_path):
     assert os.path.exists(exe)
 
 
-def _run_host(g, work):
+def _run_host(g, work, ngpu=1):
     exe = build_host.build(g.p, os.path.join(work, "beom_gpu"), variant=g.variant)
     inputs.write_inputs(work, g.files)
-    r = subprocess.run([exe], cwd=work, capture_output=True, text=True, timeout=600)
+    env = dict(os.environ)
+    if ngpu > 1:       # bands of rows on "several" devices: all of them the one GPU of the box
+        env.update(BEOM_NGPU=str(ngpu), BEOM_MULTI_WRAP_DEVICES="1")
+    r = subprocess.run([exe], cwd=work, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "ERROR CODE" not in r.stderr, (r.stdout[-1500:], r.stderr[-1500:])
     return r.stdout
 
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not HAVE_FLANG, reason="flang not present")
-@pytest.mark.parametrize("name", golden_names())
-def test_fortran_host_reproduces_reference_output_files(name):
+@pytest.mark.parametrize("name,ngpu", [(n, 1) for n in golden_names()]
+                         + [("stommel_24x16", 2), ("sill_4l_ocrp", 3), ("tide_sponge", 2), ("variant3d_3l", 2)])
+def test_fortran_host_reproduces_reference_output_files(name, ngpu):
+    """ngpu > 1: the same program with BEOM_NGPU set — the library cuts the frame into row bands
+    (beom_multi_*), the Fortran side stays one process."""
     g = Golden(name)
     work = tempfile.mkdtemp(prefix="beom_host_")
     try:
-        out = _run_host(g, work)
+        out = _run_host(g, work, ngpu)
         assert "MI355X engine" in out
+        assert ngpu == 1 or "row bands" in out
         for key in [k for k in g.z.files if k.startswith("file_")]:
             fn = key[5:].replace("_bin", ".bin").replace("_txt", ".txt")
             path = os.path.join(work, fn)
