@@ -172,6 +172,42 @@ def case_topdrag_ocrp():
     return p.replace(tdrg="1.e-3"), f
 
 
+def case_random_coast():
+    """x-periodic channel with seeded random land: blobs, one-cell islands, one-cell straits and
+    diagonal contacts — every neighbour/mask combination of index_grid_points (:588-764) that the
+    hand-made island basin may have missed.  Wind, linear drag, 2 layers."""
+    rng = np.random.RandomState(20261004)
+    lm, mm, nlay = 26, 19, 2
+    h = np.zeros((lm + 2, mm + 2))
+    h[1:-1, 1:-1] = 300.0 + 100.0 * rng.rand(lm, mm)
+    land = rng.rand(lm + 2, mm + 2) < 0.14
+    for _ in range(3):                                  # a few larger blobs
+        cx, cy, r = rng.randint(3, lm - 2), rng.randint(3, mm - 2), rng.randint(2, 4)
+        x = np.arange(lm + 2)[:, None]; y = np.arange(mm + 2)[None, :]
+        land |= ((x - cx) ** 2 + (y - cy) ** 2) <= r * r
+    h[land] = 0.0
+    h[:, 0] = 0.0; h[:, -1] = 0.0
+    h[0, :] = h[lm, :]; h[lm + 1, :] = h[1, :]          # periodic margins, as the channel recipes do
+    ndeg = I.get_nbr_deg_freedom(h)
+    x = (np.arange(lm + 2) - 0.5 * (lm + 1))[:, None]; y = (np.arange(mm + 2) - 0.5 * (mm + 1))[None, :]
+    n = np.zeros((lm + 2, mm + 2, nlay)); u = np.zeros_like(n); v = np.zeros_like(n)
+    n[:, :, 0] = 0.5 * np.exp(-(x ** 2 + y ** 2) / 30.0)
+    n[:, :, 1] = -1.5 * np.exp(-((x - 4) ** 2 + (y + 3) ** 2) / 20.0)
+    u[:, :, 0] = 0.04 * np.cos(0.5 * y) * np.ones_like(x)
+    v[:, :, 1] = 0.02 * np.sin(0.7 * x) * np.ones_like(y)
+    init = np.stack([n, u, v], axis=3)
+    taus = np.zeros((lm + 2, mm + 2, 2))
+    taus[:, :, 0] = 0.08 * np.sin(np.pi * (y / mm)) * np.ones_like(x)
+    dl = 4.0e3
+    cext = np.sqrt(9.8 * h.max())
+    dt = 0.5 * dl / cext
+    p = make_params(lm, mm, nlay, ndeg, dl, cext, 8.0e-5, [1026.0, 1028.0], [0.0, 0.4],
+                    12 * dt / 86400.0, 4 * dt / 86400.0, 0.0, 0.0, 5.0, 0.25, 3.0e-4,
+                    1.0, 10.0, 10.0, 1.0, 1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0,
+                    desc="golden: random coastline, x-periodic")
+    return p, {"h_bo": h, "init": init, "taus": taus}
+
+
 def _std_fb(pf):
     p, f = pf
     return p.replace(g_fb="0."), f
@@ -193,6 +229,7 @@ CASES = {
     "variant3d_3l": (case_3d_variant, "private_mod3d.f95"),
     "obc_mcbc0_2l": (case_obc, "private_mod.f95"),
     "biharm_island_2l": (case_biharm, "private_mod.f95"),
+    "random_coast_2l_xper": (case_random_coast, "private_mod.f95"),
     "topdrag_topo_2l": (case_topdrag, "private_mod.f95"),
     "topdrag_sill_ocrp_2l": (case_topdrag_ocrp, "private_mod.f95"),
 }

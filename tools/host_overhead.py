@@ -63,3 +63,14 @@ for (lm, mm, nlay, n) in ((256, 128, 4, 400), (4096, 1024, 4, 60)):
                                          (t5 - t4) / n * 1e3), flush=True)
     for r in runs:
         r.engine.close()
+
+# ---- the single-process form (beom_multi_*): same frame, 1 handle against 2 and 4 bands on this GPU
+import time as _t
+p, files = I.case_headline(4096, 1024, 4)
+f = read_input_data(p, files=files)
+for nb in (1, 2, 4):
+    m = capi.MultiEngine(f, devices=[0] * nb)
+    m.step(1, 10)
+    t0 = _t.perf_counter(); m.step(11, 60); t1 = _t.perf_counter()
+    print("beom_multi 4096x1024x4, %d band(s) on one GPU: %.3f ms per step, %s" % (nb, (t1 - t0) / 60 * 1e3, m.stats()), flush=True)
+    m.close()
