@@ -195,12 +195,19 @@ class SlabRunner:
         self.engine.upload(**{k: getattr(self.local_fields, k) for k in STATE_NAMES})
         self._pending = None
 
+    def _backend(self) -> str:
+        try:
+            return str(self.dist.get_backend()) if self.dist is not None and self.dist.is_initialized() else "none"
+        except Exception:
+            return "unknown"
+
     def describe(self) -> dict:
         g = self.g
         return {"ghost_rows": GHOST, "exchanges_per_step": 1, "fields": list(EXCHANGED),
                 "rows_owned": g.own1 - g.own0 + 1, "rows_local": g.rows,
                 "bytes_per_direction_per_step": len(EXCHANGED) * self.nlay * GHOST * g.L * 8,
-                "backend": "torch.distributed P2P (RCCL)", "overlap_with_interior": self.overlap}
+                "backend": "torch.distributed P2P (%s)" % ("RCCL" if self._backend() == "nccl" else self._backend()),
+                "overlap_with_interior": self.overlap}
 
     # -- packing ------------------------------------------------------------------------
     @property
