@@ -166,7 +166,7 @@ def main():
                            for i in range(NCLS) if nl[i]},
             "step_alg_GBs": B_ALG_STEP * value / 1e9, "step_frac": B_ALG_STEP * value / 1e9 / HBM_PEAK_GBS}
     traffic_file = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(traffic_file):
+    if os.path.exists(traffic_file) and world == 1 and (a.lm, a.mm, a.nlay) == (4096, 4096, 4):   # measured for that launch only
         try:
             roof["traffic"] = json.load(open(traffic_file)).get(KERNEL_ORDER[dom])
         except Exception:
