@@ -16,15 +16,12 @@
 #define TIDE_(m, ip, iv) d.tide[((m) - 1) + 2 * ((long long)(ip) + d.n1 * ((iv) - 1))]
 #define T3_(a, ip, id, il) (a)[(long long)(ip) + d.n1 * ((long long)((id) - 1) + 2 * (long long)((il) - 1))]
 
-__device__ __forceinline__ double powi_dev(double x, int n) {   // REAL**INTEGER, repeated squaring
-    double result = 1.0, base = x;
-    bool first = true;
-    while (n) {
-        if (n & 1) { result = first ? base : result * base; first = false; }
-        n >>= 1;
-        if (n) base = base * base;
-    }
-    return result;
+// REAL**INTEGER with a constant exponent as flang emits it: the left-to-right product
+// ((x*x)*x)*... (nsal is a parameter of shared_mod.f95; probed with flang 22 for n = 4..8)
+__device__ __forceinline__ double powi_dev(double x, int n) {
+    double r = x;
+    for (int q = 1; q < n; ++q) r = r * x;
+    return r;
 }
 
 // ---- first_three_timesteps prologue, private_mod.f95:2166-2177 ---------------------

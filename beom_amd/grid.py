@@ -230,16 +230,13 @@ def equilibrium_h0_noocrp(p: Params, g, h_2d) -> np.ndarray:
 
 
 def _powi(x, n):
-    """x**n for integer n by repeated squaring (what flang's integer power does)."""
-    result = None
-    base = x
-    while n:
-        if n & 1:
-            result = base if result is None else result * base
-        n >>= 1
-        if n:
-            base = base * base
-    return result
+    """x**n for a CONSTANT integer n as flang emits it: the left-to-right product ((x*x)*x)*...
+    (nsal is a parameter of shared_mod.f95; probed with flang 22 for n = 4..8 — a run-time
+    exponent would use repeated squaring, which differs in the last bit from n = 4 on)."""
+    r = x
+    for _ in range(n - 1):
+        r = r * x
+    return r
 
 
 def equilibrium_h0_ocrp(p: Params, g, h_2d) -> np.ndarray:

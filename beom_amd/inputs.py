@@ -310,3 +310,113 @@ def case_headline(lm: int = 4096, mm: int = 4096, nlay: int = 4, dvis: float = 0
                     dvis, 0.0, 1.0, 10.0, 10.0, 1.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0,
                     desc="Headline closed basin")
     return p, {"h_bo": h_bo, "init": init}
+
+
+# ---- further recipes of testcases/*.m (input halves), sizes reducible for fixtures -----------------
+
+def case_upwelling_seaward_wind(lm: int = 200, mm: int = 1, dt_s: float = 6.0, dt_o: float = 0.16667,
+                                dt_r: float = 4.0) -> Tuple[Params, Dict[str, np.ndarray]]:
+    """upwelling_seaward_wind.m:10-37 — flat 40 m channel, two layers, constant seaward wind
+    ``tauw = [0.1, 0]`` ramped over dt_r days, periodic in y, no input file but the parameters."""
+    nlay, dl, f0, hfla = 2, 1.0e3, 1.0e-4, 40.0
+    h_bo = np.zeros((lm + 2, mm + 2))
+    h_bo[1:-1, 1:-1] = hfla
+    ndeg = get_nbr_deg_freedom(h_bo)
+    cext = np.sqrt(GRAV * h_bo.max())
+    p = make_params(lm, mm, nlay, ndeg, dl, cext, f0, [1028.95, 1030.0], [0.0, 0.5], dt_s,
+                    dt_o, dt_r, 0.0, 0.0, 0.0, 0.0, 1.0, 10.0, 10.0, 1.0,
+                    0.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, tauw=(0.1, 0.0),
+                    desc="Test-case for upwelling seaward wind")
+    return p, {}
+
+
+def case_lock_exchange(lx: float = 64.0e3, mm: int = 1, dt_s: float = 5.0, dt_o: float = 1.0 / 24.0
+                       ) -> Tuple[Params, Dict[str, np.ndarray]]:
+    """lock_exchange.m:11-64 — closed 20 m flume, two layers, the interface 4 hsal below the surface
+    in the left half and 4 hsal above the bottom in the right half; f0 = 0, dvis = 0.03."""
+    hmax, nlay, dl, hmin = 20.0, 2, 400.0, 0.005
+    hsal = 10.0 * hmin
+    lm = int(round(lx / dl))
+    h_bo = hmax * np.ones((lm + 2, mm + 2))
+    h_bo[:, 0] = 0.0; h_bo[:, -1] = 0.0; h_bo[0, :] = 0.0; h_bo[-1, :] = 0.0
+    ndeg = get_nbr_deg_freedom(h_bo)
+    cext = np.sqrt(GRAV * h_bo.max())
+    n = np.zeros((lm + 2, mm + 2, nlay)); u = np.zeros_like(n); v = np.zeros_like(n)
+    half = int(round(0.5 * (lm + 2)))                     # Octave round(): half away from zero
+    n[:half, :, 1] = 0.5 * hmax - 4.0 * hsal
+    n[half:, :, 1] = -0.5 * hmax + 4.0 * hsal
+    p = make_params(lm, mm, nlay, ndeg, dl, cext, 0.0, [1025.0, 1030.0], [0.0, 0.5], dt_s,
+                    dt_o, 0.0, 0.0, 0.0, 0.03, 0.0, hmin, 10.0, 10.0, 1.0,
+                    1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0,
+                    desc="Test-case for lock-exchange")
+    return p, {"init": np.stack([n, u, v], axis=3)}
+
+
+def case_morel_upwelling(ly_in_rext: float = 1.0, lm: int = 1) -> Tuple[Params, Dict[str, np.ndarray]]:
+    """morel_upwelling.m:14-65 — x-periodic strip, coast at y_max, two layers with outcropping
+    (ocrp = 1), the wind as a body force on the top layer (bodf.bin), diag = 1."""
+    dl, nlay, hfla, hsal, f0 = 1.0e3, 2, 50.0, 0.5, 1.0e-4
+    topl, rhon = [0.0, 0.5], [1015.0, 1030.0]
+    rext = np.sqrt(GRAV * hfla) / abs(f0)
+    mm = int(round(ly_in_rext * rext / dl))
+    h_bo = np.zeros((lm + 2, mm + 2))
+    h_bo[1:-1, 1:-1] = hfla
+    ndeg = get_nbr_deg_freedom(h_bo)
+    cext = np.sqrt(GRAV * h_bo.max())
+    hmin = hsal / 10.0
+    h_1, h_2 = topl[1] * hfla, (1.0 - topl[1]) * hfla
+    r_d = np.sqrt(GRAV * (rhon[1] - rhon[0]) / rhon[1] * h_1 * h_2 / hfla) / abs(f0)
+    delt = h_1 / h_2
+    t_w = 0.05 / rhon[0] / h_1
+    t_o = abs(f0) * r_d * (1.0 + delt) / t_w
+    dt_s = float(np.floor(3.0 * t_o / 3600.0 / 24.0 + 0.5))
+    bodf = np.zeros((nlay, 2)); bodf[0, 0] = t_w
+    p = make_params(lm, mm, nlay, ndeg, dl, cext, f0, rhon, topl, dt_s,
+                    0.05 * dt_s, 0.0, 0.0, 0.0, 0.0, 0.0, hmin, 10.0, 10.0, 1.0,
+                    0.0, 0.0, 1.0, 0.0, 1.0, 0.0, 1.0,
+                    desc="Test-case: Upwelling in presence of outcrop")
+    return p, {"bodf": bodf}                     # no h_bo.bin: the flat depth comes from cext (:105-160)
+
+
+def case_outcrop_seamount(lx: float = 600.0e3, dl: float = 5.0e3, nlay: int = 5, three_d: bool = False,
+                          dt_s: float = 15.0, dt_o: float = 0.2) -> Tuple[Params, Dict[str, np.ndarray]]:
+    """outcrop_seamount.m:9-105 — closed basin deepening from the rim to 300 m with a Gaussian
+    seamount; up to five layers outcrop on the slopes (ocrp = 1); a state of rest that must stay so.
+    three_d = False is the script's x-z plane (mm = 1)."""
+    fcor, hmax = 1.0e-4, 300.0
+    if nlay == 1:
+        rhon, topl = [1000.0], [0.0]
+    else:
+        rhon = [1000.0 + 30.0 * k / (nlay - 1) for k in range(nlay)]
+        topl = [k / nlay for k in range(nlay)]
+    lm = int(np.floor(lx / dl + 0.5))
+    if lm % 2 == 0:
+        lm += 1
+    mm = lm if three_d else 1
+    xx = np.arange(1, lm + 3, dtype=np.float64)[:, None] * np.ones((1, mm + 2))
+    yy = np.ones((lm + 2, 1)) * np.arange(1, mm + 3, dtype=np.float64)[None, :]
+    xx = (xx - xx.mean()) * dl
+    yy = (yy - yy.mean()) * dl
+    ix_0 = int(np.ceil(0.5 * (mm + 2))) - 1                   # centre column (0-based)
+    h_bo = np.sqrt(xx ** 2 + yy ** 2) / dl
+    h_bo = h_bo / h_bo[:, ix_0].max() * hmax
+    h_bo = h_bo[:, ix_0].max() - h_bo
+    smnt = hmax - np.exp(-(xx ** 2 + yy ** 2) / (50.0e3) ** 2) * 0.75 * hmax
+    h_bo = np.minimum(h_bo, smnt)
+    h_bo[h_bo < h_bo[:, ix_0].min()] = 0.0
+    dhdx = np.zeros_like(h_bo); dhdy = np.zeros_like(h_bo)
+    dhdx[1:-1, :] = (h_bo[2:, :] - h_bo[:-2, :]) / (2.0 * dl)
+    dhdy[:, 1:-1] = (h_bo[:, 2:] - h_bo[:, :-2]) / (2.0 * dl)
+    slop = np.sqrt(dhdx ** 2 + dhdy ** 2)
+    hsal = 1.0 * slop[h_bo > 1.0e-3].max() * dl * (rhon[1] - rhon[0]) / rhon[1] if nlay > 1 else 1.0
+    hmin = hsal / 10.0
+    dryd = 10.0 * hsal + (nlay - 1) * hsal
+    h_bo[h_bo < dryd] = 0.0
+    h_bo[0, :] = 0.0; h_bo[-1, :] = 0.0; h_bo[:, -1] = 0.0; h_bo[:, 0] = 0.0
+    cext = np.sqrt(GRAV * h_bo.max())
+    ndeg = get_nbr_deg_freedom(h_bo)
+    p = make_params(lm, mm, nlay, ndeg, dl, cext, fcor, rhon, topl, dt_s,
+                    dt_o, 0.0, 0.0, 0.0, 0.0, 0.0, hmin, 10.0, 10.0, 1.0,
+                    1.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0,
+                    desc="Test-case for state of rest allowing isopycnal outcrop")
+    return p, {"h_bo": h_bo}

@@ -52,12 +52,14 @@ typedef struct oracle_state {
 #define IX_U 2
 #define IX_V 3
 
-/* x**n, integer n >= 1, by repeated squaring: what flang emits for REAL**INTEGER. */
+/* x**n with n an integer CONSTANT (nsal is a parameter, shared_mod.f95:105): flang emits the
+ * left-to-right product ((x*x)*x)*... — probed with flang 22 for n = 4..8; a run-time exponent
+ * would go through repeated squaring instead, which differs in the last bit from n = 4 on. */
 static inline double powi(double x, int n) {
-    double result = 1.0, base = x;
-    int first = 1;
-    while (n) {
-        if (n & 1) { result = first ? base : result * base; first = 0; }
+    double r = x;
+    for (int k = 1; k < n; ++k) r = r * x;
+    return r;
+}
         n >>= 1;
         if (n) base = base * base;
     }

@@ -208,6 +208,13 @@ def case_random_coast():
     return p, {"h_bo": h, "init": init, "taus": taus}
 
 
+def _short(pf, nsteps=12, nout=4, **lits):
+    """Same recipe, a dozen time steps (fixtures hold steps 1..10)."""
+    p, f = pf
+    dt = float(p.dt)
+    return p.replace(dt_s="%.9f" % ((nsteps + 0.2) * dt / 86400.0), dt_o="%.9f" % ((nout + 0.01) * dt / 86400.0), **lits), f
+
+
 def _std_fb(pf):
     p, f = pf
     return p.replace(g_fb="0."), f
@@ -230,6 +237,12 @@ CASES = {
     "obc_mcbc0_2l": (case_obc, "private_mod.f95"),
     "biharm_island_2l": (case_biharm, "private_mod.f95"),
     "random_coast_2l_xper": (case_random_coast, "private_mod.f95"),
+    # reduced-size runs of further testcases/*.m recipes (beom_amd/inputs.py)
+    "tc_upwelling_wind_yper": (lambda: _short(I.case_upwelling_seaward_wind(lm=40, mm=1), dt_r="0.002"), "private_mod.f95"),
+    "tc_lock_exchange": (lambda: _short(I.case_lock_exchange(lx=16.0e3)), "private_mod.f95"),
+    "tc_morel_upwelling_xper": (lambda: _short(I.case_morel_upwelling(ly_in_rext=0.2)), "private_mod.f95"),
+    "tc_outcrop_seamount_5l": (lambda: _short(I.case_outcrop_seamount(lx=200.0e3)), "private_mod.f95"),
+    "tc_outcrop_seamount_3d_3l": (lambda: _short(I.case_outcrop_seamount(lx=100.0e3, nlay=3, three_d=True)), "private_mod.f95"),
     "topdrag_topo_2l": (case_topdrag, "private_mod.f95"),
     "topdrag_sill_ocrp_2l": (case_topdrag_ocrp, "private_mod.f95"),
 }
