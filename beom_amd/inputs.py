@@ -420,3 +420,130 @@ def case_outcrop_seamount(lx: float = 600.0e3, dl: float = 5.0e3, nlay: int = 5,
                     1.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0,
                     desc="Test-case for state of rest allowing isopycnal outcrop")
     return p, {"h_bo": h_bo}
+
+
+def _frs_coefficients(n: int, extent: int, npts: int, dt: float, cext: float, dl: float, high_side: bool) -> np.ndarray:
+    """Flow-relaxation coefficients along one axis (index 1..n+2 of the frame), as every sponge
+    recipe computes them: ``dt·cext/widt · xpos/(npts − xpos)`` with xpos clipped to [0, npts − ½]
+    (Modave et al. 2010, Eq. 29; wave_sponge.m:60-88).  high_side: the E or N boundary."""
+    widt = npts * dl
+    out = np.zeros(n + 2)
+    for i in range(1, n + 3):
+        xpos = (i - 1.5 + npts - extent) if high_side else (npts - (i - 1.5))
+        xpos = min(max(xpos, 0.0), npts - 0.5)
+        out[i - 1] = dt * cext / widt * xpos / (npts - xpos)
+    return out
+
+
+def case_wave_sponge(lx: float = 600.0e3, ly: float = 600.0e3, dl: float = 10.0e3, npts: int = 15,
+                     dt_s: float = 0.25, dt_o: float = 4.17e-3) -> Tuple[Params, Dict[str, np.ndarray]]:
+    """wave_sponge.m:11-124 — flat two-layer basin, a 1 m Gaussian mound radiating into flow-relaxation
+    sponges on all four sides (eta and the normal velocity are relaxed on each side)."""
+    nlay, fcor, hfla = 2, 1.0e-4, 200.0
+    lm = int(np.floor(lx / dl + 0.5)); mm = int(np.floor(ly / dl + 0.5))
+    if lm % 2 == 0: lm += 1
+    if mm % 2 == 0: mm += 1
+    lm += 2 * npts; mm += 2 * npts
+    h_bo = np.zeros((lm + 2, mm + 2)); h_bo[1:-1, 1:-1] = hfla
+    cext = np.sqrt(GRAV * hfla)
+    ndeg = get_nbr_deg_freedom(h_bo)
+    xi = np.arange(1, lm + 3) - 1.5; yj = np.arange(1, mm + 3) - 1.5
+    xx = ((xi - np.median(xi)) * dl)[:, None] * np.ones((1, mm + 2))
+    yy = np.ones((lm + 2, 1)) * ((yj - np.median(yj)) * dl)[None, :]
+    n = np.zeros((lm + 2, mm + 2, nlay)); u = np.zeros_like(n); v = np.zeros_like(n)
+    n[:, :, 0] = 1.0 * np.exp(-(xx ** 2 + yy ** 2) / (50.0e3) ** 2)
+    dt = 0.5 * dl / cext
+    ce = _frs_coefficients(lm, lm, npts, dt, cext, dl, True)[:, None]
+    cw = _frs_coefficients(lm, lm, npts, dt, cext, dl, False)[:, None]
+    cn = _frs_coefficients(mm, mm, npts, dt, cext, dl, True)[None, :]
+    cs = _frs_coefficients(mm, mm, npts, dt, cext, dl, False)[None, :]
+    one = np.ones((lm + 2, mm + 2))
+    nudg = np.zeros((lm + 2, mm + 2, 3))
+    nudg[:, :, 0] = np.maximum.reduce([ce * one, cw * one, cn * one, cs * one])   # eta: every side
+    nudg[:, :, 1] = np.maximum(ce * one, cw * one)                                # u: E and W
+    nudg[:, :, 2] = np.maximum(cn * one, cs * one)                                # v: N and S
+    p = make_params(lm, mm, nlay, ndeg, dl, cext, fcor, [1000.0, 1030.0], [0.0, 0.5], dt_s,
+                    dt_o, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0, 10.0, 10.0, 1.0,
+                    1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0,
+                    desc="Test-case for wave sponge")
+    return p, {"init": np.stack([n, u, v], axis=3), "nudg": nudg}
+
+
+def case_tide_ridge(lm: int = 500, ocrp: int = 1, dt_s: float = 3.0, dt_o: float = 0.01, npts: int = 15,
+                    ridge_halfwidth: float = 75.0) -> Tuple[Params, Dict[str, np.ndarray]]:
+    """tide_ridge.m:6-156 — semidiurnal (M2) barotropic current over a Gaussian ridge in a 30 m deep
+    x-z plane, seven outcropping layers (three without ocrp) from an exponential density profile,
+    E/W sponges carrying the tidal u, quadratic drag switch, dvis = 0.5."""
+    hmax, bdrg, fcor, dl, mm = 30.0, 0.0, 0.0, 100.0, 1
+    dt_r = 0.75 * dt_s
+    nlay = 7 if ocrp == 1 else 3
+    if lm % 2 == 0: lm += 1
+    z = np.arange(0.0, hmax + 0.5, 1.0)
+    rhop = 1028.0 - 6.0 * np.exp(-z / (0.2 * hmax))
+    drho = (rhop.max() - rhop.min()) / nlay
+    rhon = [float(rhop.min() + (k + 0.5) * drho) for k in range(nlay)]
+    xi = (np.arange(1, lm + 3) - 1.5) * dl
+    xx = (xi - np.mean(np.repeat(xi, mm + 2)))[:, None] * np.ones((1, mm + 2))
+    h_bo = hmax - 0.75 * hmax * np.exp(-(xx / (ridge_halfwidth * dl)) ** 2)
+    h_bo[:, 0] = 0.0; h_bo[:, -1] = 0.0; h_bo[0, :] = 0.0; h_bo[-1, :] = 0.0
+    ndeg = get_nbr_deg_freedom(h_bo)
+    cext = np.sqrt(GRAV * h_bo.max())
+    dhdx = np.zeros((lm + 2, mm + 2))
+    dhdx[2:-2, :] = h_bo[3:-1, :] - h_bo[1:-3, :]
+    dhdx = dhdx / (2.0 * dl)
+    hsal = 20.0 * dhdx.max() * dl * (rhon[-1] - rhon[0]) / rhon[0]
+    hmin = hsal / 10.0
+    topl = np.interp(rhop.min() + np.arange(nlay) * drho, rhop, z)
+    if topl[1] < 10.0 * hsal:
+        topl[1:] = topl[1:] + (10.0 * hsal - topl[1])
+    topl = topl / hmax
+    tide = np.zeros((2, 1, lm + 2, mm + 2, 3))
+    tide[0, 0, :, :, 1] = 0.1
+    tide[1, 0, :, :, 1] = np.pi / 2.0
+    tide[1, 0, :, :, 2] = np.pi / 2.0
+    tide[0, 0, 0, 0, 0] = 2.0 * np.pi / (12.4206012 / 24.0)       # M2, rad/day, stored in the first element
+    dt = 0.5 * dl / cext
+    ce = _frs_coefficients(lm, lm, npts, dt, cext, dl, True)[:, None] * np.ones((1, mm + 2))
+    cw = _frs_coefficients(lm, lm, npts, dt, cext, dl, False)[:, None] * np.ones((1, mm + 2))
+    nudg = np.zeros((lm + 2, mm + 2, 3))
+    nudg[:, :, 0] = np.maximum(ce, cw); nudg[:, :, 1] = np.maximum(ce, cw)
+    p = make_params(lm, mm, nlay, ndeg, dl, cext, fcor, rhon, [float(t) for t in topl], dt_s,
+                    dt_o, dt_r, 0.0, 0.0, 0.5, bdrg, hmin, 5.0, 5.0, 1.0,
+                    1.0, 1.0, float(ocrp), 0.0, 0.0, 0.0, 0.0,
+                    desc="Test-case for tidal flow over a ridge")
+    return p, {"h_bo": h_bo, "nudg": nudg, "tide": tide}
+
+
+def case_baines_ridge(domain_in_lros: float = 150.0, npts: int = 15, dt_s: float = 10.0, dt_o: float = 0.2
+                      ) -> Tuple[Params, Dict[str, np.ndarray]]:
+    """baines_ridge.m:4-163 — uniform 1.2 m/s two-layer flow over a cosine ridge (Baines & Leonard
+    1989), y-periodic with mm = 1, the cross-stream pressure gradient as a body force, E/W sponges."""
+    hmax, u_0, nlay, fcor = 110.0, 1.2, 2, 1.0e-4
+    rhon, topl = [1025.0, 1030.0], [0.0, 1.0 / 1.1]
+    gp = GRAV * (rhon[1] - rhon[0]) / rhon[1]
+    d_0 = hmax * (1.0 - topl[1])
+    lros = np.sqrt(gp * d_0) / abs(fcor)
+    dl = lros / 5.0
+    lm = int(np.floor(domain_in_lros * lros / dl + 0.5))
+    if lm % 2 == 0: lm += 1
+    mm = 1
+    xi = (np.arange(1, lm + 3) - 1.5) * dl
+    xx = (xi - np.mean(np.repeat(xi, mm + 2)))[:, None] * np.ones((1, mm + 2))
+    h_bo = 0.1 * d_0 * np.cos(np.pi * xx / (10.0 * lros))
+    h_bo[(xx < -5.0 * lros) | (xx > 5.0 * lros)] = 0.0
+    h_bo = hmax - h_bo
+    h_bo[:, 0] = 0.0; h_bo[:, -1] = 0.0; h_bo[0, :] = 0.0; h_bo[-1, :] = 0.0
+    ndeg = get_nbr_deg_freedom(h_bo)
+    cext = np.sqrt(GRAV * h_bo.max())
+    n = np.zeros((lm + 2, mm + 2, nlay)); u = np.ones_like(n) * u_0; v = np.zeros_like(n)
+    bodf = np.zeros((nlay, 2)); bodf[:, 1] = fcor * u_0
+    dt = 0.5 * dl / cext
+    ce = _frs_coefficients(lm, lm, npts, dt, cext, dl, True)[:, None] * np.ones((1, mm + 2))
+    cw = _frs_coefficients(lm, lm, npts, dt, cext, dl, False)[:, None] * np.ones((1, mm + 2))
+    nudg = np.zeros((lm + 2, mm + 2, 3))
+    nudg[:, :, 0] = np.maximum(ce, cw); nudg[:, :, 1] = np.maximum(ce, cw)
+    p = make_params(lm, mm, nlay, ndeg, dl, cext, fcor, rhon, topl, dt_s,
+                    dt_o, 0.0, 0.0, 0.0, 0.0, 0.0, 0.1, 10.0, 10.0, 1.0,
+                    1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0,
+                    desc="Test-case for flow over a ridge")
+    return p, {"h_bo": h_bo, "init": np.stack([n, u, v], axis=3), "nudg": nudg, "bodf": bodf}

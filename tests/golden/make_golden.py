@@ -242,6 +242,10 @@ CASES = {
     "tc_lock_exchange": (lambda: _short(I.case_lock_exchange(lx=16.0e3)), "private_mod.f95"),
     "tc_morel_upwelling_xper": (lambda: _short(I.case_morel_upwelling(ly_in_rext=0.2)), "private_mod.f95"),
     "tc_outcrop_seamount_5l": (lambda: _short(I.case_outcrop_seamount(lx=200.0e3)), "private_mod.f95"),
+    "tc_wave_sponge": (lambda: _short(I.case_wave_sponge(lx=100.0e3, ly=80.0e3, npts=5)), "private_mod.f95"),
+    "tc_tide_ridge_7l": (lambda: _short(I.case_tide_ridge(lm=60, npts=5, ridge_halfwidth=10.0), dt_r="0.002"), "private_mod.f95"),
+    "tc_tide_ridge_3l_noocrp": (lambda: _short(I.case_tide_ridge(lm=60, ocrp=0, npts=5, ridge_halfwidth=10.0), dt_r="0.002"), "private_mod.f95"),
+    "tc_baines_ridge_yper": (lambda: _short(I.case_baines_ridge(domain_in_lros=14.0, npts=5)), "private_mod.f95"),
     "tc_outcrop_seamount_3d_3l": (lambda: _short(I.case_outcrop_seamount(lx=100.0e3, nlay=3, three_d=True)), "private_mod.f95"),
     "topdrag_topo_2l": (case_topdrag, "private_mod.f95"),
     "topdrag_sill_ocrp_2l": (case_topdrag_ocrp, "private_mod.f95"),
