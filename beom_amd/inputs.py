@@ -547,3 +547,126 @@ def case_baines_ridge(domain_in_lros: float = 150.0, npts: int = 15, dt_s: float
                     1.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0,
                     desc="Test-case for flow over a ridge")
     return p, {"h_bo": h_bo, "init": np.stack([n, u, v], axis=3), "nudg": nudg, "bodf": bodf}
+
+
+def case_mixed_open_bc(lm: int = 200, mm: int = 100, npts: int = 15, dt_s: float = 6.0, dt_o: float = 0.16667,
+                       dt_r: float = 4.0) -> Tuple[Params, Dict[str, np.ndarray]]:
+    """mixed_open_bc.m:4-113 — the seaward-wind upwelling with a coast in the west and open boundaries
+    elsewhere: flow relaxation of eta,u (one-month relaxation of v) in the east, one-month relaxation
+    of everything in the north and south."""
+    nlay, dl, f0, hfla = 2, 1.0e3, 1.0e-4, 40.0
+    h_bo = np.zeros((lm + 2, mm + 2)); h_bo[1:-1, 1:-1] = hfla
+    ndeg = get_nbr_deg_freedom(h_bo)
+    cext = np.sqrt(GRAV * h_bo.max())
+    dt = 0.5 * dl / cext
+    month = 31.0 * 24.0 * 3600.0
+    def slow(n, extent, high):
+        out = np.zeros(n + 2)
+        for i in range(1, n + 3):
+            xpos = (i - 1.5 + npts - extent) if high else (npts - (i - 1.5))
+            out[i - 1] = dt / month * min(max(xpos, 0.0), npts - 0.5) / npts
+        return out
+    one = np.ones((lm + 2, mm + 2))
+    ce = _frs_coefficients(lm, lm, npts, dt, cext, dl, True)[:, None] * one
+    se = slow(lm, lm, True)[:, None] * one
+    sn = slow(mm, mm, True)[None, :] * one
+    ss = slow(mm, mm, False)[None, :] * one
+    nudg = np.zeros((lm + 2, mm + 2, 3))
+    nudg[:, :, 0] = np.maximum.reduce([ce, sn, ss])
+    nudg[:, :, 1] = np.maximum.reduce([ce, sn, ss])
+    nudg[:, :, 2] = np.maximum.reduce([se, sn, ss])
+    nudg[0, :, :] = 0.0                                       # the western edge is the coast
+    p = make_params(lm, mm, nlay, ndeg, dl, cext, f0, [1028.95, 1030.0], [0.0, 0.5], dt_s,
+                    dt_o, dt_r, 0.0, 0.0, 0.0, 0.0, 0.001, 1.0, 1.0, 1.0,
+                    0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, tauw=(0.1, 0.0),
+                    desc="Test-case: Upwelling seaward wind with mixed open boundary conditions")
+    return p, {"nudg": nudg}
+
+
+def case_conservation(lx: float = 600.0e3, dl: float = 10.0e3, nlay: int = 2, outc: int = 0, topo: bool = True,
+                      xper: int = 1, yper: int = 1, dt_s: float = 50.0, dt_o: float = 0.5
+                      ) -> Tuple[Params, Dict[str, np.ndarray]]:
+    """conservation.m:4-98 — doubly periodic (by default) basin with a Gaussian seamount and a 1 m
+    surface mound of radius lx/12; standard forward-backward stepping (g_fb = 0), diag = 1;
+    outc = 1 lets the seamount pierce the deepest interfaces."""
+    fcor, hfla = 1.0e-4, 200.0
+    rhon = [1000.0 + 30.0 * (k + 1) / nlay for k in range(nlay)]
+    topl = [k / nlay for k in range(nlay)]
+    lm = int(np.floor(lx / dl + 0.5))
+    if lm % 2 == 0: lm += 1
+    mm = lm
+    xi = np.arange(1, lm + 3) - 1.5; yj = np.arange(1, mm + 3) - 1.5
+    xx = ((xi - xi.mean()) * dl)[:, None] * np.ones((1, mm + 2))
+    yy = np.ones((lm + 2, 1)) * ((yj - yj.mean()) * dl)[None, :]
+    h_bo = hfla * np.ones((lm + 2, mm + 2))
+    if topo:
+        amp = 0.5 * (2.0 - topl[-1] - topl[-2]) * hfla if outc else 0.5 * (1.0 - topl[-1]) * hfla
+        h_bo = hfla - amp * np.exp(-(xx ** 2 + yy ** 2) / (0.25 * lx) ** 2)
+    h_bo[0, :] = 0.0; h_bo[-1, :] = 0.0; h_bo[:, 0] = 0.0; h_bo[:, -1] = 0.0
+    ndeg = get_nbr_deg_freedom(h_bo)
+    n = np.zeros((lm + 2, mm + 2, nlay)); u = np.zeros_like(n); v = np.zeros_like(n)
+    n[:, :, 0] = 1.0 * np.exp(-(xx ** 2 + yy ** 2) / (lx / 12.0) ** 2)
+    cext = np.sqrt(GRAV * h_bo.max())
+    p = make_params(lm, mm, nlay, ndeg, dl, cext, fcor, rhon, topl, dt_s,
+                    dt_o, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0, 10.0, 10.0, 0.0,
+                    1.0, 0.0, float(outc), 0.0, float(xper), float(yper), 1.0,
+                    desc="Test-case for integral conservation of properties")
+    files = {"init": np.stack([n, u, v], axis=3)}
+    if topo:
+        files["h_bo"] = h_bo
+    return p, files
+
+
+def case_sill_exchange2d(lx: float | None = None, dl: float = 100.0, npts: int | None = None, tides: bool = False,
+                         sill_halfwidth: float = 200.0, dt_s: float | None = None
+                         ) -> Tuple[Params, Dict[str, np.ndarray]]:
+    """sill_exchange2D.m:6-139 and, with tides = True, sill_exchange2Dtides.m:6-165 — the x-z plane
+    form of the sill exchange: Gaussian sill of 400 m in 700 m, two outcropping layers, E/W sponges;
+    the tidal variant adds an M2 current in the sponges, starts from a different interface and uses
+    dvis = 0.5, topl = [0, 0.5]."""
+    ocrp, hmax, hsill, fcor, mm, nlay, bdrg, dt_r = 1, 700.0, 400.0, 0.00014087, 1, 2, 0.0, 0.0
+    if lx is None: lx = 100.0e3 if tides else 200.0e3
+    if npts is None: npts = 15 if tides else 200
+    if dt_s is None: dt_s = 10.0 if tides else 3.0
+    rhon = [1027.47, 1027.75]
+    topl = [0.0, 0.5] if tides else [0.0, 0.1428]
+    lm = int(np.floor(lx / dl + 0.5))
+    if lm % 2 == 0: lm += 1
+    xi = (np.arange(1, lm + 3) - 1.5) * dl
+    xx = (xi - np.mean(np.repeat(xi, mm + 2)))[:, None] * np.ones((1, mm + 2))
+    h_bo = hmax - hsill * np.exp(-(xx / (sill_halfwidth * dl)) ** 2)
+    h_bo[:, 0] = 0.0; h_bo[:, -1] = 0.0; h_bo[0, :] = 0.0; h_bo[-1, :] = 0.0
+    ndeg = get_nbr_deg_freedom(h_bo)
+    cext = np.sqrt(GRAV * h_bo.max())
+    dhdx = np.zeros((lm + 2, mm + 2))
+    dhdx[2:-2, :] = h_bo[3:-1, :] - h_bo[1:-3, :]
+    dhdx = dhdx / (2.0 * dl)
+    hsal = 20.0 * dhdx.max() * dl * (rhon[-1] - rhon[0]) / rhon[0]
+    hmin = hsal / 10.0
+    n = np.zeros((lm + 2, mm + 2, nlay)); u = np.zeros_like(n); v = np.zeros_like(n)
+    if tides:
+        half = int(np.floor(0.5 * (lm + 2) + 0.5))
+        n[:half, :, 1] = 0.5 * hmax - 4.0 * hsal - 100.0
+        right = -0.5 * hmax + 4.0 * hsal + 450.0 + (hmax - h_bo[half:, 1])
+        n[half:, :, 1] = np.minimum(right, 0.5 * hmax - 4.0 * hsal - 100.0)[:, None]
+    else:
+        j0 = int(np.floor(0.6 * (lm + 2) + 0.5))
+        n[j0:, :, 1] = (-h_bo[j0:, 1] + 500.0 + 4.0 * hsal)[:, None]
+    dt = 0.5 * dl / cext
+    ce = _frs_coefficients(lm, lm, npts, dt, cext, dl, True)[:, None] * np.ones((1, mm + 2))
+    cw = _frs_coefficients(lm, lm, npts, dt, cext, dl, False)[:, None] * np.ones((1, mm + 2))
+    nudg = np.zeros((lm + 2, mm + 2, 3))
+    nudg[:, :, 0] = np.maximum(ce, cw); nudg[:, :, 1] = np.maximum(ce, cw)
+    files = {"init": np.stack([n, u, v], axis=3), "h_bo": h_bo, "nudg": nudg}
+    if tides:
+        tide = np.zeros((2, 1, lm + 2, mm + 2, 3))
+        tide[0, 0, :, :, 1] = 0.1
+        tide[1, 0, :, :, 1] = np.pi / 2.0
+        tide[1, 0, :, :, 2] = np.pi / 2.0
+        tide[0, 0, 0, 0, 0] = 2.0 * np.pi / (12.4206012 / 24.0)
+        files["tide"] = tide
+    p = make_params(lm, mm, nlay, ndeg, dl, cext, fcor, rhon, topl, dt_s,
+                    0.01, dt_r, 0.0, 0.0, 0.5 if tides else 0.9, bdrg, hmin, 5.0, 5.0, 1.0,
+                    1.0, 1.0, float(ocrp), 0.0, 0.0, 0.0, 0.0,
+                    desc="Test-case for tidal flow over a ridge" if tides else "Test-case: 2D sill exchange")
+    return p, files

@@ -246,6 +246,11 @@ CASES = {
     "tc_tide_ridge_7l": (lambda: _short(I.case_tide_ridge(lm=60, npts=5, ridge_halfwidth=10.0), dt_r="0.002"), "private_mod.f95"),
     "tc_tide_ridge_3l_noocrp": (lambda: _short(I.case_tide_ridge(lm=60, ocrp=0, npts=5, ridge_halfwidth=10.0), dt_r="0.002"), "private_mod.f95"),
     "tc_baines_ridge_yper": (lambda: _short(I.case_baines_ridge(domain_in_lros=14.0, npts=5)), "private_mod.f95"),
+    "tc_mixed_open_bc": (lambda: _short(I.case_mixed_open_bc(lm=30, mm=24, npts=5), dt_r="0.002"), "private_mod.f95"),
+    "tc_conservation_xyper_stdfb": (lambda: _short(I.case_conservation(lx=200.0e3)), "private_mod.f95"),
+    "tc_conservation_outcrop_3l_closed": (lambda: _short(I.case_conservation(lx=200.0e3, nlay=3, outc=1, xper=0, yper=0)), "private_mod.f95"),
+    "tc_sill_exchange2d": (lambda: _short(I.case_sill_exchange2d(lx=6.0e3, npts=8, sill_halfwidth=10.0)), "private_mod.f95"),
+    "tc_sill_exchange2d_tides": (lambda: _short(I.case_sill_exchange2d(lx=6.0e3, npts=5, tides=True, sill_halfwidth=10.0)), "private_mod.f95"),
     "tc_outcrop_seamount_3d_3l": (lambda: _short(I.case_outcrop_seamount(lx=100.0e3, nlay=3, three_d=True)), "private_mod.f95"),
     "topdrag_topo_2l": (case_topdrag, "private_mod.f95"),
     "topdrag_sill_ocrp_2l": (case_topdrag_ocrp, "private_mod.f95"),
