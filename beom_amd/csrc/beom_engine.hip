@@ -455,7 +455,7 @@ static void uv_fused_swap(beom_engine *E, bool first_x) {
 }
 static void launch_uv_fused(beom_engine *E, bool first_x, bool prod, double gene, double ramp, double ctim,
                             bool swap = true) {
-    const dim3 g = uv_fused_grid(E->d), b(BEOM_BLOCK);
+    const dim3 g = uv_fused_grid(E->d), b(UV_BLOCK);
     DevView &d = E->d;
     if (first_x) {
         if (prod) hipLaunchKernelGGL((k_uv_fused<true, true>), g, b, 0, E->stream, d, gene, ramp, ctim);

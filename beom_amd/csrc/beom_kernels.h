@@ -267,6 +267,14 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_update_mont_all(DevView d) {
 #ifndef MV_UNROLL
 #define MV_UNROLL 4                    // measured: not unrolling the layer loop is 20 % slower
 #endif
+// tile of the fused u+v sweep (k_uv_fused, further down): k_mont_visc needs its geometry for lean_d2h
+#define UV_TX 64
+#define UV_Q 2
+#ifndef UV_WAVES
+#define UV_WAVES 4                     // waves (rows of 64 cells) per workgroup
+#endif
+#define UV_BLOCK (64 * UV_WAVES)
+#define UV_TY (UV_WAVES * UV_Q)
 #define MV_LDX (MV_TX + 2 + 1)          // +1 pad column
 #define MV_LDY (MV_TY + 2)
 
@@ -474,8 +482,9 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_mont_visc(DevView d) {
                           && y0 - 1 + d.joff >= 2 && y0 + MV_TY + d.joff <= d.Mg - 2;
     // d.lean_d2h (the fused u+v sweep follows): its interior workgroups re-derive d2hx, d2hy from
     // hlay; only tiles that touch a non-interior tile of that sweep (same tiling) still store them
-    const bool deep = x0 - 1 - MV_TX >= 2 && x0 + 2 * MV_TX <= d.L - 2 && y0 - 1 - MV_TY >= 2 && y0 + 2 * MV_TY <= d.M - 2
-                      && y0 - 1 - MV_TY + d.joff >= 2 && y0 + 2 * MV_TY + d.joff <= d.Mg - 2;
+    const int uy0 = ((y0 - 1) / UV_TY) * UV_TY + 1;          // first row of the k_uv_fused tile this tile lies in
+    const bool deep = x0 - 1 - UV_TX >= 2 && x0 + 2 * UV_TX <= d.L - 2 && uy0 - 1 - UV_TY >= 2 && uy0 + 2 * UV_TY <= d.M - 2
+                      && uy0 - 1 - UV_TY + d.joff >= 2 && uy0 + 2 * UV_TY + d.joff <= d.Mg - 2;
     const bool wr_d2h = !(d.lean_d2h && deep);
     if (interior) body_mont_visc<NL, true>(d, x0, y0, wr_d2h, s_rv, s_dv, s_hh);
     else body_mont_visc<NL, false>(d, x0, y0, wr_d2h, s_rv, s_dv, s_hh);
@@ -531,9 +540,6 @@ struct UVio {
 // Where a momentum update finds the five fields BOTH updates read (hlay, mont, pvor and the
 // viscous products pcd, qlr) at the cell, at its "b" neighbour (u: W, v: S) and at its "a"
 // neighbour (u: N, v: E): global memory, or the LDS image staged by the fused u+v sweep.
-#define UV_TX 64
-#define UV_Q 2
-#define UV_TY (4 * UV_Q)
 #define UV_LDX (UV_TX + 1 + 1)
 #define UV_SROWS (UV_TY + 2)
 #define UV_SLDX (UV_TX + 2)
@@ -754,7 +760,7 @@ __device__ __forceinline__ double uv_first_halo(const DevView &d, int a, int b, 
     return uv_first_eval<FIRST_X, PROD, false, false>(d, h, ilay, gene, ramp, ctim, sh);
 }
 
-static_assert(MV_TX == UV_TX && MV_TY == UV_TY, "lean_d2h: k_mont_visc decides per tile of k_uv_fused's tiling which curvatures to store");
+static_assert(MV_TX == UV_TX && UV_TY % MV_TY == 0, "lean_d2h: every tile of k_mont_visc lies inside one tile of k_uv_fused");
 // Interior workgroups of the production pair (PROD, tile and ring strictly inside the wet interior):
 // the five shared fields of tile + ring are staged in LDS once and both updates, ring cells
 // included, read them there.  All loads of a phase are issued before the first use — the
@@ -784,7 +790,7 @@ __device__ __forceinline__ void body_uv_fused_staged(const DevView &d, int x0, i
     const int lx = tid & 63, wy = tid >> 6;
     const int i = x0 + lx;
     constexpr int ROFF = FIRST_X ? 1 : 0, COFF = FIRST_X ? 0 : 1;      // s_h coordinates as in body_uv_fused
-    constexpr int NST = UV_SROWS * (UV_TX + 2), NIT = (NST + BEOM_BLOCK - 1) / BEOM_BLOCK;
+    constexpr int NST = UV_SROWS * (UV_TX + 2), NIT = (NST + UV_BLOCK - 1) / UV_BLOCK;
     const long long lay = d.n1 * (long long)(ilay - 1);
     // ---- phase A loads: stage elements, outer hlay ring, first update of own cells and of the ring cell
     const double *src[5] = {d.mont, d.pvor, d.pcd, d.qlr, d.hlay};
@@ -792,7 +798,7 @@ __device__ __forceinline__ void body_uv_fused_staged(const DevView &d, int x0, i
     int frr[NIT], fcc[NIT];
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
-        const int idx = tid + k * BEOM_BLOCK;
+        const int idx = tid + k * UV_BLOCK;
         const int idc = idx < NST ? idx : tid;           // clamped: the load is harmless, the store is skipped
         frr[k] = idc / (UV_TX + 2); fcc[k] = idc - frr[k] * (UV_TX + 2);
         const long long ip = (long long)(x0 - 1 + fcc[k]) + (long long)(y0 - 2 + frr[k]) * d.L + lay;
@@ -812,7 +818,7 @@ __device__ __forceinline__ void body_uv_fused_staged(const DevView &d, int x0, i
     double pre[UV_Q][8];
 #pragma unroll
     for (int q = 0; q < UV_Q; ++q) {
-        const int j = y0 + wy + 4 * q;
+        const int j = y0 + wy + UV_WAVES * q;
         wr[q] = row_selected(d, j);                  // cells outside the strips are evaluated, not stored
         c[q].set_cell(d, i, j);
         uv_pre_load<FIRST_X>(d, c[q], ilay, gene, true, pre[q]);
@@ -830,7 +836,7 @@ __device__ __forceinline__ void body_uv_fused_staged(const DevView &d, int x0, i
     // ---- stage
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
-        if (tid + k * BEOM_BLOCK < NST) {
+        if (tid + k * UV_BLOCK < NST) {
 #pragma unroll
             for (int f = 0; f < 4; ++f) s_f[f][frr[k]][fcc[k]] = fv[k][f];
             s_hl[frr[k] + 1][fcc[k] + 1] = fv[k][4];
@@ -846,7 +852,7 @@ __device__ __forceinline__ void body_uv_fused_staged(const DevView &d, int x0, i
     const double hs2 = 2.0 * d.hsal;
 #pragma unroll
     for (int q = 0; q < UV_Q; ++q) {
-        const int r = wy + 4 * q;
+        const int r = wy + UV_WAVES * q;
         const ShLds<FIRST_X> sh{s_f, s_hl, r + 1, lx + 1, d.ocrp, hs2};
         s_h[r + ROFF][lx + COFF] = uv_first_eval<FIRST_X, true, true, true>(d, c[q], ilay, gene, ramp, ctim, sh, wr[q], pre[q]);
     }
@@ -862,7 +868,7 @@ __device__ __forceinline__ void body_uv_fused_staged(const DevView &d, int x0, i
 #pragma unroll
     for (int q = 0; q < UV_Q; ++q) {
         if (!wr[q]) continue;
-        const int r = wy + 4 * q;
+        const int r = wy + UV_WAVES * q;
         double q0, qb, qa, qd;
         if (FIRST_X) {   // v: self, S, E, SE of h_u
             q0 = s_h[r + 1][lx]; qb = s_h[r][lx]; qa = s_h[r + 1][lx + 1]; qd = s_h[r][lx + 1];
@@ -889,7 +895,7 @@ __device__ __forceinline__ void body_uv_fused(const DevView &d, int x0, int y0, 
     bool ok[UV_Q], wr[UV_Q];
 #pragma unroll
     for (int q = 0; q < UV_Q; ++q) {
-        const int r = wy + 4 * q, j = y0 + r;
+        const int r = wy + UV_WAVES * q, j = y0 + r;
         ok[q] = (i <= d.L) && (j <= d.M);
         wr[q] = ok[q] && row_selected(d, j);       // cells outside the strips are evaluated, not stored
         c[q].set_cell(d, ok[q] ? i : 1, ok[q] ? j : 1);
@@ -930,7 +936,7 @@ __device__ __forceinline__ void body_uv_fused(const DevView &d, int x0, int y0, 
 #pragma unroll
     for (int q = 0; q < UV_Q; ++q) {
         if (!wr[q]) continue;
-        const int r = wy + 4 * q;
+        const int r = wy + UV_WAVES * q;
         double q0, qb, qa, qd;
         if (FIRST_X) {   // v: self, S, E, SE of h_u
             q0 = s_h[r + 1][lx]; qb = s_h[r][lx]; qa = s_h[r + 1][lx + 1]; qd = s_h[r][lx + 1];
@@ -945,7 +951,7 @@ __device__ __forceinline__ void body_uv_fused(const DevView &d, int x0, int y0, 
 }
 
 template <bool FIRST_X, bool PROD>
-__global__ __launch_bounds__(BEOM_BLOCK) void k_uv_fused(DevView d, double gene, double ramp, double ctim) {
+__global__ __launch_bounds__(UV_BLOCK) void k_uv_fused(DevView d, double gene, double ramp, double ctim) {
     __shared__ double s_h[UV_TY + 1][UV_LDX];
     __shared__ UVstage s_f[PROD ? 4 : 1];
     __shared__ double s_hl[PROD ? UV_HROWS : 1][UV_HLDX];
