@@ -636,7 +636,10 @@ int beom_step_phase(beom_handle E, int tstp, double tres, double dtd8, double dt
     DevView &d = E->d;
     const StepScalars s = step_scalars(E, tstp, tres, dtd8, dt_r, rsta, n_3d);
     const bool south = d.slab && d.joff > 0, north = d.slab && d.joff + d.M < d.Mg;
-    if (!(s.fused && s.fused_uv) || s.first3 || (s.stress && (E->wind || E->bot || E->top)) ||
+    // Montgomery+Leith in one sweep, or — when no viscosity refresh is due (dvis <= 1e-3, svis = 0) — the
+    // plain Montgomery sweep; the momentum sweeps must be the fused pair (out-of-place writes)
+    const bool visc_due = (E->P.dvis > 1.e-3 && s.upst) || E->P.svis > 0.0;
+    if (!(s.fused_uv && (s.fused || !visc_due)) || s.first3 || (s.stress && (E->wind || E->bot || E->top)) ||
         !(south || north) || d.M < 32 || (phase != 1 && phase != 2) || E->obc) {
         set_err(errm, errm_len, "beom_step_phase: split step not available for this step/configuration");
         return -20;
@@ -649,12 +652,12 @@ int beom_step_phase(beom_handle E, int tstp, double tres, double dtd8, double dt
         set_rows(d, 1, south ? 9 : 1, north ? M - 8 : M);
         if (T) T->begin(0);
         launch_h(E, s.gene, s.ramp, s.ctim, false);
-        if (T) { T->end(); T->begin(5); }
+        if (T) { T->end(); T->begin(s.fused ? 5 : 1); }
         set_rows(d, 1, south ? 10 : 1, north ? M - 9 : M);
-        launch_mont_visc(E, true);
+        if (s.fused) launch_mont_visc(E, true); else launch_mont(E, 0);
         if (T) { T->end(); T->begin(6); }
         set_rows(d, 1, south ? 11 : 1, north ? M - 10 : M);
-        launch_uv_fused(E, u_first, true, s.gene, s.ramp, s.ctim, false);
+        launch_uv_fused(E, u_first, s.fused, s.gene, s.ramp, s.ctim, false);
         if (T) T->end();
     } else {
         // edge strips; a side without a neighbour has no strip (its rows were done in phase 1)
@@ -666,12 +669,12 @@ int beom_step_phase(beom_handle E, int tstp, double tres, double dtd8, double dt
         strips(8);
         if (T) T->begin(0);
         launch_h(E, s.gene, s.ramp, s.ctim, true);
-        if (T) { T->end(); T->begin(5); }
+        if (T) { T->end(); T->begin(s.fused ? 5 : 1); }
         strips(9);
-        launch_mont_visc(E, true);
+        if (s.fused) launch_mont_visc(E, true); else launch_mont(E, 0);
         if (T) { T->end(); T->begin(6); }
         strips(10);
-        launch_uv_fused(E, u_first, true, s.gene, s.ramp, s.ctim, true);
+        launch_uv_fused(E, u_first, s.fused, s.gene, s.ramp, s.ctim, true);
         if (T) T->end();
     }
     set_rows(d, 1, 1, M);

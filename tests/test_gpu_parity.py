@@ -317,7 +317,8 @@ def test_profile_start_stop_counts_launches():
     e.close()
 
 
-@pytest.mark.parametrize("case,world", [("closed_tall", 2), ("closed_tall", 3), ("sill_tall", 2)])
+@pytest.mark.parametrize("case,world", [("closed_tall", 2), ("closed_tall", 3), ("sill_tall", 2), ("beach_tall_noleith", 2),
+                                        ("soliton_tall_noleith", 3)])
 def test_split_step_with_late_ghosts_matches_single_domain(case, world):
     """beom_step_phase: phase 1 (interior rows) runs BEFORE the ghost rows of the previous step
     are refreshed, phase 2 (rows next to the ghost zones) after — the order the overlapped
@@ -327,6 +328,10 @@ def test_split_step_with_late_ghosts_matches_single_domain(case, world):
     from beom_amd.grid import read_input_data
     if case == "closed_tall":
         p, files = I.case_headline(150, 131, 3)
+    elif case == "beach_tall_noleith":      # dvis = 0: plain Montgomery sweep + fused u+v in the split step
+        p, files = I.case_carrier_beach(lm=140, mm=150, nlay=2, dt_s=0.08)
+    elif case == "soliton_tall_noleith":
+        p, files = I.case_soliton(lm=141, mm=151, dt_s=5.0)
     else:
         p, files = I.case_sill_exchange3d(lm=133, mm=141, nlay=2, dt_s=0.01, npts=5, sill_halfwidth=6.0)
     f = read_input_data(p, files=files)
@@ -466,7 +471,8 @@ def test_device_side_output_records(name):
     e.close()
 
 
-@pytest.mark.parametrize("case,nband", [("closed_tall", 3), ("sill_tall", 2), ("stommel_tall", 2), ("soliton_xper", 2)])
+@pytest.mark.parametrize("case,nband", [("closed_tall", 3), ("sill_tall", 2), ("stommel_tall", 2), ("soliton_xper", 2),
+                                        ("beach_tall_noleith", 3)])
 def test_one_process_several_bands_match_single_handle(case, nband):
     """beom_multi_* (the single-process multi-GPU form the Fortran host uses): bands of rows, ghost
     exchange by peer copy on second streams, overlapped split steps — here with every band on
@@ -479,6 +485,7 @@ def test_one_process_several_bands_match_single_handle(case, nband):
         "sill_tall": lambda: I.case_sill_exchange3d(lm=133, mm=199, nlay=4, dt_s=0.01, npts=5, sill_halfwidth=20.0),
         "stommel_tall": lambda: I.case_stommel(lm=140, mm=150, dl=50.0e3, dt_s=0.2),
         "soliton_xper": lambda: I.case_soliton(lm=141, mm=63, dt_s=5.0),
+        "beach_tall_noleith": lambda: I.case_carrier_beach(lm=140, mm=260, nlay=2, dt_s=0.08),
     }[case]()
     f = read_input_data(p, files=files)
     one = capi.Engine(f)
@@ -497,7 +504,7 @@ def test_one_process_several_bands_match_single_handle(case, nband):
         assert same(a[k], b[k]), (case, k, "after 23 steps")
     st = many.stats()
     assert st["split"] + st["plain"] == 23 * nband
-    if case == "closed_tall":                          # unforced, fused: every step after the 3rd of a call sequence is split
+    if case in ("closed_tall", "beach_tall_noleith"):  # every step after the 3rd of a call sequence is split
         assert st["split"] >= 15 * nband, st
     one.close(); many.close()
 
