@@ -12,8 +12,10 @@ for a host reference inside a test, so size-independent properties of the scheme
     to rounding;
   * dense path == gather path on a band of rows would need two 16 GB states, so instead the
     fused and the unfused sweeps are compared bitwise after the same 6 steps.
-configs[4] (8192x8192x8, 8 GPUs) is out of reach of a 1-GPU test; its recipe (carrier beach,
-ocrp=1) is covered at 120x3 by the golden fixture and at 2048x64x2 here."""
+configs[4] (8192x8192x8, 8 GPUs) is too long for this suite; its recipe (carrier beach, ocrp=1) is
+covered at 120x3 by the golden fixture and at 2048x64x2 here, and tools/config5_slab_size.py runs the
+full frame on one GPU — single handle against eight row bands, bit for bit
+(profiles/r01_config5_full_frame.txt)."""
 import numpy as np
 import pytest
 

@@ -19,7 +19,13 @@ p, files = I.case_carrier_beach(lm=8192, mm=mm, nlay=8, dt_s=0.08)
 print("recipe %.0f s" % (time.time() - t0), flush=True)
 f = read_input_data(p, files=files)
 del files
+import resource
+def rss_gb():
+    return resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6
+if rss_gb() > 215.0:
+    raise SystemExit("host state needs %.0f GB: too close to the box's memory cap" % rss_gb())
 print("host state %.0f s, ndeg=%d nlay=%d (%.1f M cell-layers)" % (time.time() - t0, p.ndeg, p.nlay, p.ndeg * p.nlay / 1e6), flush=True)
+print("host peak RSS %.1f GB" % (__import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss / 1e6), flush=True)
 one = capi.Engine(f)
 assert one.is_dense
 one.step(1, 3)
@@ -37,5 +43,6 @@ same = {k: bool(np.array_equal(ref[k], got[k])) for k in ref}
 print(json.dumps({"frame": "8192x%dx8 carrier beach, ocrp=1" % mm, "bands": nb, "steps": 3 + K,
                   "single_ms_per_step": round(ms1, 2), "banded_ms_per_step_one_gpu": round(msn, 2),
                   "bitwise_equal": same, "band_steps": st, "finite": bool(np.isfinite(got["hlay"]).all()),
-                  "max_abs_u": float(np.max(np.abs(got["u"]))), "wall_s": round(time.time() - t0)}), flush=True)
+                  "max_abs_u": float(np.max(np.abs(got["u"]))), "wall_s": round(time.time() - t0),
+                  "host_peak_rss_GB": round(rss_gb(), 1)}), flush=True)
 assert all(same.values())
