@@ -439,8 +439,10 @@ static void launch_uv(beom_engine *E, int ilay, double gene, double ramp, double
 static bool launch_mont_visc(beom_engine *E, bool uv_fused_follows) {
     const dim3 g = mont_visc_grid(E->d), b(BEOM_BLOCK);
     E->d.lean_d2h = uv_fused_follows && E->lean_d2h && !E->d.keep_diag;
+    const bool leith = E->P.dvis > 1.e-3;          // else: the products of the standing v_cc, v_ll
     switch (E->d.nlay) {
-#define CASE_NL(n) case n: hipLaunchKernelGGL((k_mont_visc<n>), g, b, 0, E->stream, E->d); return true;
+#define CASE_NL(n) case n: if (leith) hipLaunchKernelGGL((k_mont_visc<n, true>), g, b, 0, E->stream, E->d); \
+                           else hipLaunchKernelGGL((k_mont_visc<n, false>), g, b, 0, E->stream, E->d); return true;
         CASE_NL(1) CASE_NL(2) CASE_NL(3) CASE_NL(4) CASE_NL(5) CASE_NL(6) CASE_NL(8)
 #undef CASE_NL
         default: return false;
@@ -466,10 +468,14 @@ static void launch_uv_fused(beom_engine *E, bool first_x, bool prod, double gene
     }
     if (swap) uv_fused_swap(E, first_x);
 }
-static bool can_fuse(const beom_engine *E, int n_3d) {
-    // every step must refresh the viscosity (else v_cc/v_ll have to persist): dvis > 1e-3 and n_3d = 1 (:2268)
+static bool can_fuse(const beom_engine *E, int n_3d, bool first3) {
+    // either every step refreshes the viscosity (dvis > 1e-3 and n_3d = 1, :2268) — Montgomery + Leith
+    // in one sweep — or no step after the third ever does (dvis <= 1e-3, svis = 0): v_cc, v_ll stand
+    // and the sweep forms their products with this step's dive, rvor
     const int nl = E->d.nlay;
-    return E->dense && E->fuse && E->P.dvis > 1.e-3 && n_3d == 1 && (nl <= 6 || nl == 8) && !(E->P.svis > 0.0);
+    if (!(E->dense && E->fuse && (nl <= 6 || nl == 8)) || E->P.svis > 0.0) return false;
+    if (E->P.dvis > 1.e-3) return n_3d == 1;
+    return !first3;                               // steps 1-3 call update_viscosity unconditionally (:2188)
 }
 static void launch_stress(beom_engine *E) {
     if (!(E->wind || E->bot || E->top)) return;
@@ -515,7 +521,7 @@ static StepScalars step_scalars(const beom_engine *E, int tstp, double tres, dou
         s.stress = s.upst;                                         // :1894-1896
     }
     s.gene = s.first3 ? 0.0 : E->P.g_fb;                           // :1859,1877
-    s.fused = can_fuse(E, n_3d);
+    s.fused = can_fuse(E, n_3d, s.first3);
     s.fused_uv = E->dense && E->fuse_uv && !(E->P.svis > 0.0);
     return s;
 }

@@ -305,7 +305,10 @@ __device__ __forceinline__ bool halo_target(const DevView &d, int &a, int &b) {
     return true;
 }
 
-template <int NL, bool INT>
+// LEITH = false: configurations whose viscosity is never refreshed after the first three steps
+// (dvis <= 1e-3, svis = 0): v_cc, v_ll keep whatever update_viscosity left there (:2188) and only
+// the products with this step's dive, rvor are formed — no ring of rvor/dive is needed.
+template <int NL, bool INT, bool LEITH>
 __device__ __forceinline__ void body_mont_visc(const DevView &d, int x0, int y0, bool wr_d2h,
                                                double (*s_rv)[MV_LDY][MV_LDX], double (*s_dv)[MV_LDY][MV_LDX],
                                                double (*s_hh)[MV_LDY][MV_LDX]) {
@@ -362,15 +365,16 @@ __device__ __forceinline__ void body_mont_visc(const DevView &d, int x0, int y0,
     for (int l = 0; l < NL; ++l) {      // must stay unrolled: d.rhon[l] may not become a dynamic index
         const int ilay = l + 1, buf = l & 1;
         // every load of this layer first ...
-        double w[MV_Q][6], wh[6], hring = 0.0;
+        double w[MV_Q][6], wh[6], hring = 0.0, vcc0[MV_Q], vll0[MV_Q];
 #pragma unroll
         for (int q = 0; q < MV_Q; ++q) {
             if (INT || ok[q]) uv6_load<INT>(d, c[q], ilay, w[q]);
             else { w[q][0] = w[q][1] = w[q][2] = w[q][3] = w[q][4] = w[q][5] = 0.0; }
+            if (!LEITH) { vcc0[q] = LL(d.v_cc, c[q].ipnt, ilay); vll0[q] = LL(d.v_ll, c[q].ipnt, ilay); }
         }
         if (hr >= 0) {
             hring = LL(d.hlay, hidx, ilay);
-            if (hidx != 0) uv6_load<INT>(d, hcell, ilay, wh);
+            if (LEITH && hidx != 0) uv6_load<INT>(d, hcell, ilay, wh);
         }
         // ... then the arithmetic and the stage
         double rv[MV_Q], dv[MV_Q];
@@ -382,7 +386,7 @@ __device__ __forceinline__ void body_mont_visc(const DevView &d, int x0, int y0,
             if (!INT && widx[q] >= 0) {                  // rare: orphan column/row, cells beyond the frame
                 srv = 0.0; sdv = 0.0;                    // sentinel: rvor(0) = dive(0) = 0 (:273,275)
                 shh = LL(d.hlay, widx[q], ilay);
-                if (widx[q] > 0) {
+                if (LEITH && widx[q] > 0) {
                     int a = i, b = y0 + wy + 4 * q;
                     halo_target<INT>(d, a, b);
                     CellDenseT<INT> t; t.set_cell(d, a, b);
@@ -391,15 +395,19 @@ __device__ __forceinline__ void body_mont_visc(const DevView &d, int x0, int y0,
                     rv_dv_calc<INT>(d, t, wt, srv, sdv);
                 }
             }
-            s_rv[buf][1 + wy + 4 * q][1 + lx] = srv;
-            s_dv[buf][1 + wy + 4 * q][1 + lx] = sdv;
+            if (LEITH) {
+                s_rv[buf][1 + wy + 4 * q][1 + lx] = srv;
+                s_dv[buf][1 + wy + 4 * q][1 + lx] = sdv;
+            }
             s_hh[buf][1 + wy + 4 * q][1 + lx] = shh;
         }
         if (hr >= 0) {
-            double a = 0.0, b = 0.0;
-            if (hidx != 0) rv_dv_calc<INT>(d, hcell, wh, a, b);
-            s_rv[buf][hr][hc] = a;
-            s_dv[buf][hr][hc] = b;
+            if (LEITH) {
+                double a = 0.0, b = 0.0;
+                if (hidx != 0) rv_dv_calc<INT>(d, hcell, wh, a, b);
+                s_rv[buf][hr][hc] = a;
+                s_dv[buf][hr][hc] = b;
+            }
             s_hh[buf][hr][hc] = hring;
         }
         __syncthreads();
@@ -443,35 +451,40 @@ __device__ __forceinline__ void body_mont_visc(const DevView &d, int x0, int y0,
             }
             const double have = h0 + hW + h6 + hS;
             LL(d.pvor, ipnt, ilay) = (fcor[q] + rv[q] * d.uadv) * mkpi * (mkn + mk5 + mk6 + mk7) / have;
-            // Leith viscosity from the staged ring (same names as :2458-2470)
-            const double r_bl = rv[q], r_br = s_rv[buf][r][cx + 1], r_tr = s_rv[buf][r + 1][cx + 1],
-                         r_tl = s_rv[buf][r + 1][cx], rbll = s_rv[buf][r][cx - 1], rbbl = s_rv[buf][r - 1][cx];
-            const double d_cc = dv[q], d_ri = s_dv[buf][r][cx + 1], d_to = s_dv[buf][r + 1][cx],
-                         d_le = s_dv[buf][r][cx - 1], d_bl = s_dv[buf][r - 1][cx - 1], d_bo = s_dv[buf][r - 1][cx];
-            double a = (r_br - r_bl) * (r_br - r_bl) + (r_bl - rbll) * (r_bl - rbll)
-                     + (r_tl - r_bl) * (r_tl - r_bl) + (r_bl - rbbl) * (r_bl - rbbl)
-                     + (d_cc - d_le) * (d_cc - d_le) + (d_bo - d_bl) * (d_bo - d_bl)
-                     + (d_cc - d_bo) * (d_cc - d_bo) + (d_le - d_bl) * (d_le - d_bl);
-            const double vll = sqrt(a) * d.dvis * d.dl * d.dl + d.bvis;
-            double b = (r_br - r_bl) * (r_br - r_bl) + (r_tr - r_tl) * (r_tr - r_tl)
-                     + (r_tl - r_bl) * (r_tl - r_bl) + (r_tr - r_br) * (r_tr - r_br)
-                     + (d_ri - d_cc) * (d_ri - d_cc) + (d_cc - d_le) * (d_cc - d_le)
-                     + (d_to - d_cc) * (d_to - d_cc) + (d_cc - d_bo) * (d_cc - d_bo);
-            const double vcc = sqrt(b) * d.dvis * d.dl * d.dl + d.bvis;
+            const double r_bl = rv[q], d_cc = dv[q];
+            double vcc, vll;
+            if (LEITH) {       // Leith viscosity from the staged ring (same names as :2458-2470)
+                const double r_br = s_rv[buf][r][cx + 1], r_tr = s_rv[buf][r + 1][cx + 1],
+                             r_tl = s_rv[buf][r + 1][cx], rbll = s_rv[buf][r][cx - 1], rbbl = s_rv[buf][r - 1][cx];
+                const double d_ri = s_dv[buf][r][cx + 1], d_to = s_dv[buf][r + 1][cx],
+                             d_le = s_dv[buf][r][cx - 1], d_bl = s_dv[buf][r - 1][cx - 1], d_bo = s_dv[buf][r - 1][cx];
+                double a = (r_br - r_bl) * (r_br - r_bl) + (r_bl - rbll) * (r_bl - rbll)
+                         + (r_tl - r_bl) * (r_tl - r_bl) + (r_bl - rbbl) * (r_bl - rbbl)
+                         + (d_cc - d_le) * (d_cc - d_le) + (d_bo - d_bl) * (d_bo - d_bl)
+                         + (d_cc - d_bo) * (d_cc - d_bo) + (d_le - d_bl) * (d_le - d_bl);
+                vll = sqrt(a) * d.dvis * d.dl * d.dl + d.bvis;
+                double b = (r_br - r_bl) * (r_br - r_bl) + (r_tr - r_tl) * (r_tr - r_tl)
+                         + (r_tl - r_bl) * (r_tl - r_bl) + (r_tr - r_br) * (r_tr - r_br)
+                         + (d_ri - d_cc) * (d_ri - d_cc) + (d_cc - d_le) * (d_cc - d_le)
+                         + (d_to - d_cc) * (d_to - d_cc) + (d_cc - d_bo) * (d_cc - d_bo);
+                vcc = sqrt(b) * d.dvis * d.dl * d.dl + d.bvis;
+            } else {
+                vcc = vcc0[q]; vll = vll0[q];
+            }
             LL(d.pcd, ipnt, ilay) = vcc * d_cc;
             LL(d.qlr, ipnt, ilay) = vll * r_bl;
             if (d.keep_diag) {
                 LL(d.rvor, ipnt, ilay) = r_bl; LL(d.dive, ipnt, ilay) = d_cc;
-                LL(d.v_cc, ipnt, ilay) = vcc;  LL(d.v_ll, ipnt, ilay) = vll;
+                if (LEITH) { LL(d.v_cc, ipnt, ilay) = vcc; LL(d.v_ll, ipnt, ilay) = vll; }
             }
         }
     }
 }
 
-template <int NL>
+template <int NL, bool LEITH = true>
 __global__ __launch_bounds__(BEOM_BLOCK) void k_mont_visc(DevView d) {
-    __shared__ double s_rv[2][MV_LDY][MV_LDX];
-    __shared__ double s_dv[2][MV_LDY][MV_LDX];
+    __shared__ double s_rv[LEITH ? 2 : 1][LEITH ? MV_LDY : 1][LEITH ? MV_LDX : 1];
+    __shared__ double s_dv[LEITH ? 2 : 1][LEITH ? MV_LDY : 1][LEITH ? MV_LDX : 1];
     __shared__ double s_hh[2][MV_LDY][MV_LDX];               // hlay of tile + ring
     const TileMap tm(d, MV_TX, MV_TY);
     int ty, ch;
@@ -486,8 +499,8 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_mont_visc(DevView d) {
     const bool deep = x0 - 1 - UV_TX >= 2 && x0 + 2 * UV_TX <= d.L - 2 && uy0 - 1 - UV_TY >= 2 && uy0 + 2 * UV_TY <= d.M - 2
                       && uy0 - 1 - UV_TY + d.joff >= 2 && uy0 + 2 * UV_TY + d.joff <= d.Mg - 2;
     const bool wr_d2h = !(d.lean_d2h && deep);
-    if (interior) body_mont_visc<NL, true>(d, x0, y0, wr_d2h, s_rv, s_dv, s_hh);
-    else body_mont_visc<NL, false>(d, x0, y0, wr_d2h, s_rv, s_dv, s_hh);
+    if (interior) body_mont_visc<NL, true, LEITH>(d, x0, y0, wr_d2h, (double (*)[MV_LDY][MV_LDX])s_rv, (double (*)[MV_LDY][MV_LDX])s_dv, s_hh);
+    else body_mont_visc<NL, false, LEITH>(d, x0, y0, wr_d2h, (double (*)[MV_LDY][MV_LDX])s_rv, (double (*)[MV_LDY][MV_LDX])s_dv, s_hh);
 }
 static inline dim3 mont_visc_grid(const DevView &d) { return dim3(TileMap(d, MV_TX, MV_TY).blocks(), 1, 1); }
 

@@ -11,6 +11,7 @@ def _case():
             "jet": lambda: I.case_unstable_jet(lm=2048, mm=2048, nlay=2, dt_s=50.0),
             "sill": lambda: I.case_sill_exchange3d(lm=4096, mm=512, nlay=4, dt_s=30.0, npts=15, sill_halfwidth=50.0),
             "stommel": lambda: I.case_stommel(lm=128, mm=128, dl=100.0e3, dt_s=400.0),
+            "beach": lambda: I.case_carrier_beach(lm=8192, mm=1024, nlay=8, dt_s=0.08),   # one GPU's share of config 5
             "headline_gather": lambda: I.case_headline(4096, 4096, 4),     # same frame through the neig tables
             "headline_land": lambda: with_land(I.case_headline(4096, 4096, 4)),
             }[case]()
