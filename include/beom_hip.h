@@ -164,7 +164,9 @@ int beom_unpack_rows(beom_handle h, int jlo, int nrows, const void *device_buffe
  *  "fuse_mont_visc" (default 1): with the Leith viscosity refreshed every step (dvis > 1e-3,
  *      n_3d = 1) update_mont... and update_viscosity run as ONE sweep that hands update_u/v
  *      the products v_cc*dive and v_ll*rvor; v_cc, v_ll, rvor, dive are then kept up to date
- *      only with "keep_diag" = 1 (default 0).
+ *      only with "keep_diag" = 1 (default 0).  With dvis <= 1e-3 (and svis = 0) the same sweep,
+ *      from step 4 on, forms the products of the standing v_cc, v_ll instead (rvor, dive again
+ *      only with "keep_diag").
  *  "fuse_uv" (default 1): update_u and update_v of a step run as ONE sweep.
  *  "fuse": sets both.  0 = always five separate sweeps.
  * Returns -3 for an unknown name. */
