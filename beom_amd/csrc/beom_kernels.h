@@ -628,6 +628,9 @@ __device__ __forceinline__ double uv_core(const C &c, const DevView &d, int ilay
                              : (h_self + sh.hlay_b()) / (1.0 + mask);
     // pre (staged fused sweep): [0] this cell's velocity, [5..7] its history levels, loaded ahead of use
     double vold = pre ? pre[0] : LL(io.vel_in, ipnt, ilay);
+    // nudging terms (wave-uniform switch): fetched up front, not next to their use further down
+    double f_fn = 0.0, f_ng = 0.0;
+    if (d.has_nudg) { f_fn = FNUD_(ipnt, ilay, IV); f_ng = NUDG_(ipnt, IV); }
     const double dmd4 = (sh.mont_b() - m_self) * i_dl * d.grav * mask;
     const double pva = sh.pvor_a();
     double rhsi = dmd4 * (1.0 - gene);
@@ -672,7 +675,7 @@ __device__ __forceinline__ double uv_core(const C &c, const DevView &d, int ilay
     // in the sign of an exact zero, so those (rare) lanes alone go through the full expression.
     if (d.has_nudg || vold == 0.0) {
         const double i__hh = 1.0 / (hcen + 1.0 - mask);
-        double vfor = FNUD_(ipnt, ilay, IV);
+        double vfor = d.has_nudg ? f_fn : FNUD_(ipnt, ilay, IV);
         if (d.has_stress) {
             const double ek = 0.5 * (T3_(d.tt3d, ipnt, IO, ilay) + T3_(d.tt3d, cb, IO, ilay))
                               * i_r1 * d.invf * i__hh * ramp;
@@ -682,7 +685,7 @@ __device__ __forceinline__ double uv_core(const C &c, const DevView &d, int ilay
         }
         if (d.has_tide) vfor = vfor + ramp * TIDE_(1, ipnt, IV) * cos(TIDE_(2, ipnt, IV) - d.w_ti * ctim);
         else vfor = vfor + 0.0;                                         // ramp*0*cos(0)
-        const double ng = d.has_nudg ? NUDG_(ipnt, IV) : 0.0;
+        const double ng = d.has_nudg ? f_ng : 0.0;
         vold = vfor * ng + vold * (1.0 - ng);
     }
     const double hnew = 0.5 * (vold + fabs(vold)) * (hcen - 0.16667 * sh.template d2h_b<XDIR>())
