@@ -59,6 +59,7 @@ __device__ __forceinline__ void body_update_h(const C &c, const DevView &d, doub
     const int ilay_lo = gridDim.y == 1 ? 1 : (int)blockIdx.y + 1;
     for (int ilay = ilay_hi; ilay >= ilay_lo; --ilay) {
         double hold = LL(d.hlay, ipnt, ilay);
+        const double hfor0 = FORCED ? FNUD_(ipnt, ilay, 1) : 0.0;        // fetched with the rest, used at the end
         const double hu0 = LL(d.h_u, ipnt, ilay);
         double huE;
         if (C::kLanesAreRowNeighbours) {        // flux divergence in x: east value by wavefront shuffle
@@ -84,7 +85,7 @@ __device__ __forceinline__ void body_update_h(const C &c, const DevView &d, doub
         // unforced: hfor*0 + (1-0)*hold with hfor = fnud_n >= +0  ==  (+0) + hold (turns -0 into +0)
         double hnew = 0.0 + hold;
         if (FORCED) {
-            double hfor = FNUD_(ipnt, ilay, 1);
+            double hfor = hfor0;
             if (FORCE > 1) {
                 const double vecl = (ilay == 1) ? 1.0 : 0.0;
                 hfor = hfor + ramp * TIDE_(1, ipnt, 1) * vecl * cos(TIDE_(2, ipnt, 1) - d.w_ti * ctim);
