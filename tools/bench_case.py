@@ -12,6 +12,7 @@ def _case():
             "sill": lambda: I.case_sill_exchange3d(lm=4096, mm=512, nlay=4, dt_s=30.0, npts=15, sill_halfwidth=50.0),
             "stommel": lambda: I.case_stommel(lm=128, mm=128, dl=100.0e3, dt_s=400.0),
             "beach": lambda: I.case_carrier_beach(lm=8192, mm=1024, nlay=8, dt_s=0.08),   # one GPU's share of config 5
+            "wind": lambda: I.case_mixed_open_bc(lm=4096, mm=2048, npts=15),   # wind-driven, nudged, 2 layers
             "headline_gather": lambda: I.case_headline(4096, 4096, 4),     # same frame through the neig tables
             "headline_land": lambda: with_land(I.case_headline(4096, 4096, 4)),
             }[case]()
