@@ -41,6 +41,8 @@ struct DevView {
     int lean_d2h;                 // fused sweep stores d2hx, d2hy only where the fused u+v sweep reads them
     // biharmonic viscosity (svis > 0, :2508-2599): Laplacians and thickness-weighted fluxes
     double *delu, *delv, *uu4, *vv4; double svis;
+    // packed layout: per run of 64 cells (dN, dS) if the run is a uniform wet interior, else (0, 0); may be null
+    const int32_t *woff;
     // nudged open-boundary segments, Fortran segm(nseg, 18) (no_gradient_obc, :2613-2679)
     const int32_t *segm; int nseg;
     // stress work arrays
@@ -97,6 +99,28 @@ template <int K> struct NbOff {
 };
 
 // Any coastline: neighbours and masks come from the caller's tables.
+// Packed (table) layout, a wave whose 64 cells are all wet interior cells with wet neighbours at the
+// same index offsets (E/W = +-1, N = +dN, S = -dS for the whole wave; beom_create builds the per-wave
+// table woff): neighbours by arithmetic, every mask 1 — no table traffic, as in the dense interior.
+struct CellPackedInt {
+    static constexpr bool kLanesAreRowNeighbours = true;
+    int ipnt, dN, dS;
+    const DevView *dv;
+    template <int K> __device__ __forceinline__ int nb() const {
+        constexpr int di = NbOff<K>::di, dj = NbOff<K>::dj;
+        return ipnt + di + (dj > 0 ? dN : (dj < 0 ? -dS : 0));
+    }
+    __device__ __forceinline__ double mk_n() const { return 1.0; }
+    __device__ __forceinline__ double mk_u() const { return 1.0; }
+    __device__ __forceinline__ double mk_v() const { return 1.0; }
+    __device__ __forceinline__ double mkpe() const { return 1.0; }
+    __device__ __forceinline__ double mkpi() const { return 1.0; }
+    template <int K> __device__ __forceinline__ double mk_n_nb(int) const { return 1.0; }
+    __device__ __forceinline__ int isub() const { return dv->subc[ipnt]; }
+    __device__ __forceinline__ bool wave_is_interior() const { return true; }
+    __device__ __forceinline__ const CellPackedInt &as_interior() const { return *this; }
+};
+
 struct CellGather {
     static constexpr bool kLanesAreRowNeighbours = false;
     int ipnt;
@@ -119,8 +143,17 @@ struct CellGather {
     __device__ __forceinline__ double mkpi() const { return dv->mkpi[ipnt]; }
     template <int K> __device__ __forceinline__ double mk_n_nb(int c) const { return dv->mk_n[c]; }
     __device__ __forceinline__ int isub() const { return dv->subc[ipnt]; }
-    __device__ __forceinline__ bool wave_is_interior() const { return false; }
-    __device__ __forceinline__ const CellGather &as_interior() const { return *this; }
+    // wave-uniform (a 256-thread workgroup = four aligned runs of 64 packed cells)
+    __device__ __forceinline__ bool wave_is_interior() const {
+        if (!dv->woff) return false;
+        const int w = __builtin_amdgcn_readfirstlane((ipnt - 1) >> 6);
+        return dv->woff[2 * w] != 0;
+    }
+    __device__ __forceinline__ CellPackedInt as_interior() const {
+        const int w = __builtin_amdgcn_readfirstlane((ipnt - 1) >> 6);
+        CellPackedInt r; r.ipnt = ipnt; r.dN = dv->woff[2 * w]; r.dS = dv->woff[2 * w + 1]; r.dv = dv;
+        return r;
+    }
 };
 
 // Dense frame (interior entirely wet; every BASELINE config).  Closed form of SURVEY

@@ -52,6 +52,7 @@ struct beom_engine {
     float *h0r4_dev = nullptr, *out4[3] = {nullptr, nullptr, nullptr};   // device-side output staging
     double *scan_dev = nullptr;
     int any_u = 0, any_v = 0;
+    long long uniform_waves = 0, total_waves = 0;   // table path: runs of 64 cells handled by offset arithmetic
     bool obc = false;                  // no_gradient_obc active (flag_nudging, mcbc < 0.5, segments set)
     bool fuse = true;                  // dense frames: Montgomery+Leith in one sweep (k_mont_visc)
     bool fuse_uv = true;               // dense frames: update_u + update_v in one sweep (k_uv_fused)
@@ -203,6 +204,30 @@ int beom_create(const beom_params *prm, int device, const int32_t *neig, const i
     UP(tide, tide, 6 * n1) UP(bodf, bodf, 2 * nl) UP(taus, taus, 2 * n1)
 #undef UP
     for (size_t i = 0; i < n1; ++i) { if (mk_u[i] > 0.5) E->any_u = 1; if (mk_v[i] > 0.5) E->any_v = 1; }
+    d.woff = nullptr;
+    if (!E->dense && getenv("BEOM_NO_WAVE_TABLE") == nullptr) {      // table path: which runs of 64 cells are uniform interior?
+        const long long nw = ((long long)prm->ndeg + 63) / 64;
+        std::vector<int32_t> woff((size_t)(2 * nw), 0);
+        long long nuni = 0;
+        for (long long w = 0; w < nw; ++w) {
+            const long long p0 = 64 * w + 1;
+            if (p0 + 63 > prm->ndeg) break;
+            const int32_t *r0 = neig + 8 * p0;
+            const int dN = r0[2] - (int)p0, dS = (int)p0 - r0[6];
+            bool ok = dN > 0 && dS > 0 && r0[2] != 0 && r0[6] != 0;
+            for (long long p = p0; ok && p < p0 + 64; ++p) {
+                const int32_t *r = neig + 8 * p;
+                ok = r[0] == p + 1 && r[4] == p - 1 && r[2] == p + dN && r[6] == p - dS &&
+                     r[1] == p + dN + 1 && r[3] == p + dN - 1 && r[5] == p - dS - 1 && r[7] == p - dS + 1 &&
+                     r[3] >= 1 && r[5] >= 1 && r[1] <= prm->ndeg &&
+                     mk_u[p] == 1.0 && mk_v[p] == 1.0 && mk_n[p] == 1.0 && mkpe[p] == 1.0 && mkpi[p] == 1.0;
+                for (int q = 0; ok && q < 8; ++q) ok = mk_n[r[q]] == 1.0;
+            }
+            if (ok) { woff[2 * w] = dN; woff[2 * w + 1] = dS; ++nuni; }
+        }
+        E->uniform_waves = nuni; E->total_waves = nw;
+        if (nuni > 0 && (rc = dev_upload(E, &d.woff, woff.data(), (size_t)(2 * nw), errm, errm_len))) { beom_destroy(E); return rc; }
+    }
     d.has_hdot = any_nonzero(hdot, nl * n1);
     d.has_tide = any_nonzero(tide, 6 * n1);
     d.has_bodf = any_nonzero(bodf, 2 * nl);
