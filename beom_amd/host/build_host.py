@@ -55,7 +55,7 @@ def build(p: Optional[Params], out_exe: str, shared_mod_path: Optional[str] = No
         os.makedirs(os.path.dirname(out_exe), exist_ok=True)
         # the fork's extra switches exist only in a shared_mod.f95 that declares them
         fork = ["-DBEOM_FORK_SWITCHES"] if re.search(r"^[^!]*\bsvis\s*=", open(shared_mod_path).read(), re.M) else []
-        cmd = [FLANG, opt, "-cpp", *fork, "-ffp-contract=off", shared_mod_path, os.path.join(HERE, "beom_cabi.f95"),
+        cmd = [FLANG, opt, "-cpp", *fork, "-ffp-contract=off", *os.environ.get("BEOM_FLANG_EXTRA", "").split(), shared_mod_path, os.path.join(HERE, "beom_cabi.f95"),
                host_src, main_path, "-L" + CSRC, "-lbeom_hip",
                "-Wl,-rpath," + CSRC, "-o", out_exe]
         r = subprocess.run(cmd, cwd=work, capture_output=True, text=True)

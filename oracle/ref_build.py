@@ -169,7 +169,7 @@ def build(params, out_dir: str, variant: str = "private_mod.f95", openmp: bool =
             with open(os.path.join(scratch, name), "w") as f:
                 f.write(txt)
         exe = os.path.join(out_dir, "beom_ref")
-        cmd = [FLANG, opt, "-ffp-contract=off"]
+        cmd = [FLANG, opt, "-ffp-contract=off"] + os.environ.get("BEOM_FLANG_EXTRA", "").split()
         if openmp:
             cmd.append("-fopenmp")
         cmd += ["shared_mod.f95", "private_mod.f95", os.path.join(REF, "main.f95"), "-o", exe]

@@ -13,9 +13,18 @@ OUT = os.path.join(ROOT, "oracle", "_ref", "e2e")
 NSTEPS, NOUT = 4000, 1000
 
 
+WHICH = os.environ.get("BEOM_E2E_CASE", "soliton")       # soliton (BASELINE config 2) | jet (config 3)
+if WHICH == "jet":
+    NSTEPS, NOUT = 400, 200
+    OUT = os.path.join(ROOT, "oracle", "_ref", "e2e_jet")
+
+
 def case():
     from beom_amd import inputs as I
-    p, files = I.case_soliton(lm=2048, mm=256, dt_s=1.0)
+    if WHICH == "jet":
+        p, files = I.case_unstable_jet(lm=2048, mm=2048, nlay=2, dt_s=50.0)
+    else:
+        p, files = I.case_soliton(lm=2048, mm=256, dt_s=1.0)
     dt = float(p.dt)
     p = p.replace(dt_s="%.9f" % ((NSTEPS + 0.2) * dt / 86400.0), dt_o="%.9f" % ((NOUT + 0.01) * dt / 86400.0))
     assert p.nstp == NSTEPS and p.notp == NOUT, (p.nstp, p.notp)
@@ -37,7 +46,7 @@ def run():
     from beom_amd import inputs as I
     p, files = case()
     threads = oracle_lib.host_cores()
-    res = {"case": "soliton 2048x256x1, %d steps, output every %d" % (NSTEPS, NOUT), "cpu_threads": threads}
+    res = {"case": "%s %dx%dx%d, %d steps, output every %d" % (WHICH, p.lm, p.mm, p.nlay, NSTEPS, NOUT), "cpu_threads": threads}
     dirs = {}
     for who, exe in (("gpu", os.path.join(OUT, "gpu", "beom_gpu")), ("ref", os.path.join(OUT, "ref", "beom_ref"))):
         wd = tempfile.mkdtemp(prefix="beom_e2e_%s_" % who)
