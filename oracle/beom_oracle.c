@@ -60,11 +60,6 @@ static inline double powi(double x, int n) {
     for (int k = 1; k < n; ++k) r = r * x;
     return r;
 }
-        n >>= 1;
-        if (n) base = base * base;
-    }
-    return result;
-}
 
 /* ---- update_h, private_mod.f95:1593-1646 (variant 0) and
  *      private_mod3d.f95:1593-1689 (variant 1) ----------------------------------- */
