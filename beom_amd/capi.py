@@ -73,6 +73,18 @@ _lib = None
 ERRLEN = 999                       # lstr of shared_mod.f95:34
 
 
+def source_hash() -> str:
+    """The hash the Makefile embeds: sha1 of the library's sources in the Makefile's order."""
+    import hashlib
+    csrc = os.path.join(_HERE, "csrc")
+    h = hashlib.sha1()
+    for fn in ("beom_engine.hip", "beom_multi.hip", "beom_dev.h", "beom_kernels.h",
+               os.path.join("..", "..", "include", "beom_hip.h")):
+        with open(os.path.join(csrc, fn), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def load(path: Optional[str] = None) -> C.CDLL:
     """Loads libbeom_hip.so and declares every prototype of include/beom_hip.h."""
     global _lib
@@ -90,6 +102,12 @@ def load(path: Optional[str] = None) -> C.CDLL:
         raise RuntimeError("HIP engine library %s not built (run __graft_entry__.build()); "
                            "there is no CPU fallback" % path)
     lib = C.CDLL(path)
+    if path == LIB_PATH and os.environ.get("BEOM_HIP_LIB") is None:      # in-tree library: must match the in-tree sources
+        lib.beom_source_hash.restype = C.c_char_p
+        built, tree = lib.beom_source_hash().decode(), source_hash()
+        if built != tree:
+            raise RuntimeError("libbeom_hip.so was built from other sources (%s, tree %s): run "
+                               "__graft_entry__.build()" % (built, tree))
     dpp, ipp, cp, ci, cd = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_char_p, C.c_int, C.c_double
     H = C.c_void_p
     lib.beom_abi_version.restype = ci

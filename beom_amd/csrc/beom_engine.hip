@@ -132,6 +132,10 @@ bool verify_dense(int L, int M, int joff, int Mg, int slab, int xper, int yper, 
 
 extern "C" {
 
+#ifndef BEOM_SRC_HASH
+#define BEOM_SRC_HASH "unknown"
+#endif
+const char *beom_source_hash(void) { return BEOM_SRC_HASH; }
 int beom_abi_version(void) { return BEOM_ABI_VERSION; }
 
 int beom_device_count(char *errm, int errm_len) {

@@ -74,6 +74,8 @@ typedef struct beom_engine *beom_handle;
 
 /* Version/ABI probe (no GPU needed). */
 int beom_abi_version(void);
+/* sha1 prefix of the sources the library was built from (Makefile); bindings compare it with the tree. */
+const char *beom_source_hash(void);
 /* Number of visible HIP devices, or a negative error code. */
 int beom_device_count(char *errm, int errm_len);
 

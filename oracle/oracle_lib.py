@@ -55,8 +55,10 @@ def load():
     if _lib is None:
         # small fixtures: a big OpenMP team only adds barrier cost (256-way on the GPU box)
         os.environ.setdefault("OMP_NUM_THREADS", str(min(8, host_cores())))
-        if not os.path.exists(LIB):
-            build()
+        src = os.path.join(HERE, "beom_oracle.c")
+        stale = os.path.exists(LIB) and os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(LIB) + 1.0
+        if not os.path.exists(LIB) or stale:
+            build()                    # raises if the C restatement does not compile: never run a stale checker
         _lib = C.CDLL(LIB)
         cd, ci = C.c_double, C.c_int
         PP, SP = C.POINTER(BeomParams), C.POINTER(OracleState)

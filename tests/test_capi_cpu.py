@@ -31,6 +31,13 @@ def test_library_exports_every_declared_symbol():
     assert lib.beom_abi_version() == capi.BEOM_ABI_VERSION
 
 
+def test_library_was_built_from_these_sources():
+    """The Makefile embeds a hash of the sources; the binding refuses a stale library."""
+    lib = capi.load()
+    lib.beom_source_hash.restype = ctypes.c_char_p
+    assert lib.beom_source_hash().decode() == capi.source_hash()
+
+
 def test_params_struct_size_matches_oracle_build():
     import oracle_lib
     oracle_lib.load()          # asserts sizeof(beom_params) == ctypes size
