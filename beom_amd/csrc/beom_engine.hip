@@ -465,10 +465,12 @@ static void launch_uv(beom_engine *E, int ilay, double gene, double ramp, double
     if (!copy_hist) { if (XDIR) rot3(E->d.dmx); else rot3(E->d.dmy); }
 }
 // fused Montgomery + Leith sweep (dense frames); false if no instantiation for this nlay
-static bool launch_mont_visc(beom_engine *E, bool uv_fused_follows) {
+// leith: this step refreshes the Leith viscosity (:2188, :2268); else the sweep forms the products of the
+// standing v_cc, v_ll.  keep_visc: a refreshed viscosity has to stand for later steps (n_3d > 1).
+static bool launch_mont_visc(beom_engine *E, bool uv_fused_follows, bool leith, bool keep_visc) {
     const dim3 g = mont_visc_grid(E->d), b(BEOM_BLOCK);
     E->d.lean_d2h = uv_fused_follows && E->lean_d2h && !E->d.keep_diag;
-    const bool leith = E->P.dvis > 1.e-3;          // else: the products of the standing v_cc, v_ll
+    E->d.keep_visc = keep_visc;
     switch (E->d.nlay) {
 #define CASE_NL(n) case n: if (leith) hipLaunchKernelGGL((k_mont_visc<n, true>), g, b, 0, E->stream, E->d); \
                            else hipLaunchKernelGGL((k_mont_visc<n, false>), g, b, 0, E->stream, E->d); return true;
@@ -503,7 +505,8 @@ static bool can_fuse(const beom_engine *E, int n_3d, bool first3) {
     // and the sweep forms their products with this step's dive, rvor
     const int nl = E->d.nlay;
     if (!(E->dense && E->fuse && (nl <= 6 || nl == 8)) || E->P.svis > 0.0) return false;
-    if (E->P.dvis > 1.e-3) return n_3d == 1;
+    (void)n_3d;
+    if (E->P.dvis > 1.e-3) return true;           // refresh steps: Leith in the sweep; others: standing v_cc, v_ll
     return !first3;                               // steps 1-3 call update_viscosity unconditionally (:2188)
 }
 static void launch_stress(beom_engine *E) {
@@ -532,7 +535,7 @@ int beom_distribute_stress(beom_handle E) { NEED(E); launch_stress(E); return 0;
 }  // extern "C"
 
 // Per-step scalars of integrate_time (private_mod.f95:1858-1901).
-struct StepScalars { double ctim, ramp, gene; bool first3, upst, stress, fused, fused_uv; };
+struct StepScalars { double ctim, ramp, gene; bool first3, upst, stress, fused, fused_uv; int n_3d; };
 static StepScalars step_scalars(const beom_engine *E, int tstp, double tres, double dtd8, double dt_r,
                                 double rsta, int n_3d) {
     StepScalars s;
@@ -550,6 +553,7 @@ static StepScalars step_scalars(const beom_engine *E, int tstp, double tres, dou
         s.stress = s.upst;                                         // :1894-1896
     }
     s.gene = s.first3 ? 0.0 : E->P.g_fb;                           // :1859,1877
+    s.n_3d = n_3d;
     s.fused = can_fuse(E, n_3d, s.first3);
     s.fused_uv = E->dense && E->fuse_uv && !(E->P.svis > 0.0);
     return s;
@@ -570,7 +574,8 @@ static void one_step(beom_engine *E, int tstp, const StepScalars &s) {
     if (T) T->begin(0);
     launch_h(E, s.gene, s.ramp, s.ctim);                           // :2181,2259
     if (T) { T->end(); T->begin(s.fused ? 5 : 1); }
-    const bool prod = s.fused && launch_mont_visc(E, s.fused_uv);              // :2187-2188, 2266-2269 in one sweep
+    const bool leith = E->P.dvis > 1.e-3 && s.upst;
+    const bool prod = s.fused && launch_mont_visc(E, s.fused_uv, leith, leith && s.n_3d > 1);              // :2187-2188, 2266-2269 in one sweep
     if (!prod) launch_mont(E, 0);
     if (T) T->end();
     if (!prod && (s.first3 || (E->P.dvis > 1.e-3 && s.upst) || E->P.svis > 0.0)) {     // :2188,2268
@@ -689,7 +694,7 @@ int beom_step_phase(beom_handle E, int tstp, double tres, double dtd8, double dt
         launch_h(E, s.gene, s.ramp, s.ctim, false);
         if (T) { T->end(); T->begin(s.fused ? 5 : 1); }
         set_rows(d, 1, south ? 10 : 1, north ? M - 9 : M);
-        if (s.fused) launch_mont_visc(E, true); else launch_mont(E, 0);
+        if (s.fused) launch_mont_visc(E, true, E->P.dvis > 1.e-3 && s.upst, E->P.dvis > 1.e-3 && s.upst && s.n_3d > 1); else launch_mont(E, 0);
         if (T) { T->end(); T->begin(6); }
         set_rows(d, 1, south ? 11 : 1, north ? M - 10 : M);
         launch_uv_fused(E, u_first, s.fused, s.gene, s.ramp, s.ctim, false);
@@ -706,7 +711,7 @@ int beom_step_phase(beom_handle E, int tstp, double tres, double dtd8, double dt
         launch_h(E, s.gene, s.ramp, s.ctim, true);
         if (T) { T->end(); T->begin(s.fused ? 5 : 1); }
         strips(9);
-        if (s.fused) launch_mont_visc(E, true); else launch_mont(E, 0);
+        if (s.fused) launch_mont_visc(E, true, E->P.dvis > 1.e-3 && s.upst, E->P.dvis > 1.e-3 && s.upst && s.n_3d > 1); else launch_mont(E, 0);
         if (T) { T->end(); T->begin(6); }
         strips(10);
         launch_uv_fused(E, u_first, s.fused, s.gene, s.ramp, s.ctim, true);

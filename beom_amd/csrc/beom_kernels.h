@@ -477,6 +477,8 @@ __device__ __forceinline__ void body_mont_visc(const DevView &d, int x0, int y0,
             if (d.keep_diag) {
                 LL(d.rvor, ipnt, ilay) = r_bl; LL(d.dive, ipnt, ilay) = d_cc;
                 if (LEITH) { LL(d.v_cc, ipnt, ilay) = vcc; LL(d.v_ll, ipnt, ilay) = vll; }
+            } else if (LEITH && d.keep_visc) {       // refreshed every n_3d > 1 steps: must stand until the next refresh
+                LL(d.v_cc, ipnt, ilay) = vcc; LL(d.v_ll, ipnt, ilay) = vll;
             }
         }
     }

@@ -168,7 +168,8 @@ int beom_unpack_rows(beom_handle h, int jlo, int nrows, const void *device_buffe
  *      the products v_cc*dive and v_ll*rvor; v_cc, v_ll, rvor, dive are then kept up to date
  *      only with "keep_diag" = 1 (default 0).  With dvis <= 1e-3 (and svis = 0) the same sweep,
  *      from step 4 on, forms the products of the standing v_cc, v_ll instead (rvor, dive again
- *      only with "keep_diag").
+ *      only with "keep_diag"); with n_3d > 1 the refresh steps also store v_cc, v_ll and the
+ *      steps in between use that standing-viscosity form.
  *  "fuse_uv" (default 1): update_u and update_v of a step run as ONE sweep.
  *  "fuse": sets both.  0 = always five separate sweeps.
  * Returns -3 for an unknown name. */

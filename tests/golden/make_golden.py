@@ -215,6 +215,12 @@ def _short(pf, nsteps=12, nout=4, **lits):
     return p.replace(dt_s="%.9f" % ((nsteps + 0.2) * dt / 86400.0), dt_o="%.9f" % ((nout + 0.01) * dt / 86400.0), **lits), f
 
 
+def _with_dt3d(pf, nsteps3d=3):
+    """Viscosity and stresses refreshed every nsteps3d steps only (dt3d > 0, :1889-1896)."""
+    p, f = pf
+    return p.replace(dt3d="%.9f" % ((nsteps3d + 0.2) * float(p.dt) / 86400.0)), f
+
+
 def _std_fb(pf):
     p, f = pf
     return p.replace(g_fb="0."), f
@@ -236,6 +242,8 @@ CASES = {
     "variant3d_3l": (case_3d_variant, "private_mod3d.f95"),
     "obc_mcbc0_2l": (case_obc, "private_mod.f95"),
     "biharm_island_2l": (case_biharm, "private_mod.f95"),
+    "jet_2l_xyper_dt3d": (lambda: _with_dt3d(I.case_unstable_jet(lm=21, mm=27, nlay=2, dt_s=1.5, dt_o=0.45)), "private_mod.f95"),
+    "stommel_24x16_dt3d": (lambda: _with_dt3d(I.case_stommel(lm=24, mm=16, dl=100.0e3, dt_s=0.2), 2), "private_mod.f95"),
     "random_coast_2l_xper": (case_random_coast, "private_mod.f95"),
     # reduced-size runs of further testcases/*.m recipes (beom_amd/inputs.py)
     "tc_upwelling_wind_yper": (lambda: _short(I.case_upwelling_seaward_wind(lm=40, mm=1), dt_r="0.002"), "private_mod.f95"),

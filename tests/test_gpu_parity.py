@@ -53,7 +53,7 @@ def _fuses(p):
     viscosity is refreshed every step, or never after step 3."""
     if float(p.svis) > 0.0 or not (p.nlay <= 6 or p.nlay == 8):
         return False
-    return p.n_3d == 1 if float(p.dvis) > 1e-3 else True
+    return True
 
 
 def _fusion_active(g, e):
