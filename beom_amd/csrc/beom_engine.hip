@@ -435,7 +435,7 @@ static bool launch_mont_all(beom_engine *E) {
     const dim3 g = CTX::grid(E->d, 1), b(BEOM_BLOCK);
     switch (E->d.nlay) {
 #define CASE_NL(n) case n: hipLaunchKernelGGL((k_update_mont_all<CTX, n>), g, b, 0, E->stream, E->d); return true;
-        CASE_NL(1) CASE_NL(2) CASE_NL(3) CASE_NL(4) CASE_NL(5) CASE_NL(6) CASE_NL(8)
+        CASE_NL(1) CASE_NL(2) CASE_NL(3) CASE_NL(4) CASE_NL(5) CASE_NL(6) CASE_NL(7) CASE_NL(8)
 #undef CASE_NL
         default: return false;
     }
@@ -474,7 +474,7 @@ static bool launch_mont_visc(beom_engine *E, bool uv_fused_follows, bool leith, 
     switch (E->d.nlay) {
 #define CASE_NL(n) case n: if (leith) hipLaunchKernelGGL((k_mont_visc<n, true>), g, b, 0, E->stream, E->d); \
                            else hipLaunchKernelGGL((k_mont_visc<n, false>), g, b, 0, E->stream, E->d); return true;
-        CASE_NL(1) CASE_NL(2) CASE_NL(3) CASE_NL(4) CASE_NL(5) CASE_NL(6) CASE_NL(8)
+        CASE_NL(1) CASE_NL(2) CASE_NL(3) CASE_NL(4) CASE_NL(5) CASE_NL(6) CASE_NL(7) CASE_NL(8)
 #undef CASE_NL
         default: return false;
     }
@@ -504,7 +504,7 @@ static bool can_fuse(const beom_engine *E, int n_3d, bool first3) {
     // in one sweep — or no step after the third ever does (dvis <= 1e-3, svis = 0): v_cc, v_ll stand
     // and the sweep forms their products with this step's dive, rvor
     const int nl = E->d.nlay;
-    if (!(E->dense && E->fuse && (nl <= 6 || nl == 8)) || E->P.svis > 0.0) return false;
+    if (!(E->dense && E->fuse && nl <= 8) || E->P.svis > 0.0) return false;
     (void)n_3d;
     if (E->P.dvis > 1.e-3) return true;           // refresh steps: Leith in the sweep; others: standing v_cc, v_ll
     return !first3;                               // steps 1-3 call update_viscosity unconditionally (:2188)

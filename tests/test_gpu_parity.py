@@ -51,7 +51,7 @@ def _engine(f, variant=0, mode="dense_fused", **kw):
 def _fuses(p):
     """Montgomery(+Leith) runs as the fused sweep for this configuration (beom_engine.hip can_fuse): the
     viscosity is refreshed every step, or never after step 3."""
-    if float(p.svis) > 0.0 or not (p.nlay <= 6 or p.nlay == 8):
+    if float(p.svis) > 0.0 or p.nlay > 8:
         return False
     return True
 
