@@ -479,7 +479,7 @@ def test_device_side_output_records(name):
 
 
 @pytest.mark.parametrize("case,nband", [("closed_tall", 3), ("sill_tall", 2), ("stommel_tall", 2), ("soliton_xper", 2),
-                                        ("beach_tall_noleith", 3)])
+                                        ("beach_tall_noleith", 3), ("closed_tall_dt3d", 3)])
 def test_one_process_several_bands_match_single_handle(case, nband):
     """beom_multi_* (the single-process multi-GPU form the Fortran host uses): bands of rows, ghost
     exchange by peer copy on second streams, overlapped split steps — here with every band on
@@ -493,6 +493,9 @@ def test_one_process_several_bands_match_single_handle(case, nband):
         "stommel_tall": lambda: I.case_stommel(lm=140, mm=150, dl=50.0e3, dt_s=0.2),
         "soliton_xper": lambda: I.case_soliton(lm=141, mm=63, dt_s=5.0),
         "beach_tall_noleith": lambda: I.case_carrier_beach(lm=140, mm=260, nlay=2, dt_s=0.08),
+        # Leith viscosity refreshed every 3rd step only: the bands keep v_cc, v_ll standing in between
+        "closed_tall_dt3d": lambda: (lambda pf: (pf[0].replace(dt3d="%.9f" % (3.2 * float(pf[0].dt) / 86400.0)), pf[1]))(
+            I.case_headline(150, 260, 3)),
     }[case]()
     f = read_input_data(p, files=files)
     one = capi.Engine(f)
