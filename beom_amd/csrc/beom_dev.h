@@ -39,6 +39,7 @@ struct DevView {
     double *pcd, *qlr;
     int keep_diag;                // fused sweep also stores rvor, dive, v_cc, v_ll
     int keep_visc;                // fused sweep (Leith) also stores v_cc, v_ll: they stand for n_3d - 1 more steps
+    int zero_visc;                // v_cc = v_ll = +0 everywhere and never refreshed: the viscous products are +-0
     int lean_d2h;                 // fused sweep stores d2hx, d2hy only where the fused u+v sweep reads them
     // biharmonic viscosity (svis > 0, :2508-2599): Laplacians and thickness-weighted fluxes
     double *delu, *delv, *uu4, *vv4; double svis;

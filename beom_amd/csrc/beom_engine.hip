@@ -56,6 +56,8 @@ struct beom_engine {
     bool obc = false;                  // no_gradient_obc active (flag_nudging, mcbc < 0.5, segments set)
     bool fuse = true;                  // dense frames: Montgomery+Leith in one sweep (k_mont_visc)
     bool fuse_uv = true;               // dense frames: update_u + update_v in one sweep (k_uv_fused)
+    bool lean_visc = true;             // zero viscosity (dvis = bvis = 0, v_cc = v_ll = +0): fused pair drops the viscous products
+    bool visc_all_zero = true;         // no non-(+0) v_cc / v_ll has been uploaded
     bool lean_d2h = true;              // fused pair: d2hx, d2hy re-derived from hlay in k_uv_fused, not stored by k_mont_visc
     char last_err[512] = {0};
 };
@@ -350,6 +352,9 @@ int beom_upload_state(beom_handle E, const double *hlay, const double *u, const 
     if ((rc = hist_in(E, d.dmy, 3, dmdy, errm, errm_len))) return rc;
     // a caller may upload stresses computed elsewhere: keep those terms live
     if (any_nonzero(tt3d, 2 * n) || any_nonzero(tb3d, 2 * n) || any_nonzero(tu3d, 2 * n)) d.has_stress = 1;
+    // zero-viscosity shortcut: only while v_cc, v_ll are +0 bit for bit (-0 would flip the sign of the products)
+    for (const double *a : {v_cc, v_ll})
+        if (a) for (size_t i = 0; i < n && E->visc_all_zero; ++i) { uint64_t b; memcpy(&b, &a[i], 8); if (b != 0) E->visc_all_zero = false; }
     HIP_TRY(hipStreamSynchronize(E->stream));
     return 0;
 }
@@ -471,6 +476,8 @@ static bool launch_mont_visc(beom_engine *E, bool uv_fused_follows, bool leith, 
     const dim3 g = mont_visc_grid(E->d), b(BEOM_BLOCK);
     E->d.lean_d2h = uv_fused_follows && E->lean_d2h && !E->d.keep_diag;
     E->d.keep_visc = keep_visc;
+    E->d.zero_visc = !leith && uv_fused_follows && E->lean_visc && E->visc_all_zero && E->P.dvis == 0.0 && E->P.bvis == 0.0 &&
+                     !E->d.keep_diag;
     switch (E->d.nlay) {
 #define CASE_NL(n) case n: if (leith) hipLaunchKernelGGL((k_mont_visc<n, true>), g, b, 0, E->stream, E->d); \
                            else hipLaunchKernelGGL((k_mont_visc<n, false>), g, b, 0, E->stream, E->d); return true;
@@ -490,11 +497,14 @@ static void launch_uv_fused(beom_engine *E, bool first_x, bool prod, double gene
                             bool swap = true) {
     const dim3 g = uv_fused_grid(E->d), b(UV_BLOCK);
     DevView &d = E->d;
+    const bool zv = prod && d.zero_visc;          // set by launch_mont_visc of this step
     if (first_x) {
-        if (prod) hipLaunchKernelGGL((k_uv_fused<true, true>), g, b, 0, E->stream, d, gene, ramp, ctim);
+        if (zv) hipLaunchKernelGGL((k_uv_fused<true, true, true>), g, b, 0, E->stream, d, gene, ramp, ctim);
+        else if (prod) hipLaunchKernelGGL((k_uv_fused<true, true>), g, b, 0, E->stream, d, gene, ramp, ctim);
         else hipLaunchKernelGGL((k_uv_fused<true, false>), g, b, 0, E->stream, d, gene, ramp, ctim);
     } else {
-        if (prod) hipLaunchKernelGGL((k_uv_fused<false, true>), g, b, 0, E->stream, d, gene, ramp, ctim);
+        if (zv) hipLaunchKernelGGL((k_uv_fused<false, true, true>), g, b, 0, E->stream, d, gene, ramp, ctim);
+        else if (prod) hipLaunchKernelGGL((k_uv_fused<false, true>), g, b, 0, E->stream, d, gene, ramp, ctim);
         else hipLaunchKernelGGL((k_uv_fused<false, false>), g, b, 0, E->stream, d, gene, ramp, ctim);
     }
     if (swap) uv_fused_swap(E, first_x);
@@ -832,6 +842,7 @@ int beom_set_option(beom_handle E, const char *name, int value) {
     else if (!strcmp(name, "fuse_uv")) E->fuse_uv = value != 0;
     else if (!strcmp(name, "keep_diag")) E->d.keep_diag = value != 0;
     else if (!strcmp(name, "lean_d2h")) E->lean_d2h = value != 0;
+    else if (!strcmp(name, "lean_visc")) E->lean_visc = value != 0;
     else return -3;
     return 0;
 }

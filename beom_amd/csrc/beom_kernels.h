@@ -310,7 +310,7 @@ __device__ __forceinline__ bool halo_target(const DevView &d, int &a, int &b) {
 // (dvis <= 1e-3, svis = 0): v_cc, v_ll keep whatever update_viscosity left there (:2188) and only
 // the products with this step's dive, rvor are formed — no ring of rvor/dive is needed.
 template <int NL, bool INT, bool LEITH>
-__device__ __forceinline__ void body_mont_visc(const DevView &d, int x0, int y0, bool wr_d2h,
+__device__ __forceinline__ void body_mont_visc(const DevView &d, int x0, int y0, bool wr_d2h, bool wr_prod,
                                                double (*s_rv)[MV_LDY][MV_LDX], double (*s_dv)[MV_LDY][MV_LDX],
                                                double (*s_hh)[MV_LDY][MV_LDX]) {
     const int tid = threadIdx.x;
@@ -371,7 +371,10 @@ __device__ __forceinline__ void body_mont_visc(const DevView &d, int x0, int y0,
         for (int q = 0; q < MV_Q; ++q) {
             if (INT || ok[q]) uv6_load<INT>(d, c[q], ilay, w[q]);
             else { w[q][0] = w[q][1] = w[q][2] = w[q][3] = w[q][4] = w[q][5] = 0.0; }
-            if (!LEITH) { vcc0[q] = LL(d.v_cc, c[q].ipnt, ilay); vll0[q] = LL(d.v_ll, c[q].ipnt, ilay); }
+            if (!LEITH) {     // zero_visc: v_cc = v_ll = +0 everywhere (dvis = bvis = 0), verified by the engine
+                vcc0[q] = d.zero_visc ? 0.0 : LL(d.v_cc, c[q].ipnt, ilay);
+                vll0[q] = d.zero_visc ? 0.0 : LL(d.v_ll, c[q].ipnt, ilay);
+            }
         }
         if (hr >= 0) {
             hring = LL(d.hlay, hidx, ilay);
@@ -472,8 +475,10 @@ __device__ __forceinline__ void body_mont_visc(const DevView &d, int x0, int y0,
             } else {
                 vcc = vcc0[q]; vll = vll0[q];
             }
-            LL(d.pcd, ipnt, ilay) = vcc * d_cc;
-            LL(d.qlr, ipnt, ilay) = vll * r_bl;
+            if (LEITH || wr_prod) {       // (+0)*dive, (+0)*rvor: only the boundary workgroups of k_uv_fused read them
+                LL(d.pcd, ipnt, ilay) = vcc * d_cc;
+                LL(d.qlr, ipnt, ilay) = vll * r_bl;
+            }
             if (d.keep_diag) {
                 LL(d.rvor, ipnt, ilay) = r_bl; LL(d.dive, ipnt, ilay) = d_cc;
                 if (LEITH) { LL(d.v_cc, ipnt, ilay) = vcc; LL(d.v_ll, ipnt, ilay) = vll; }
@@ -502,8 +507,9 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_mont_visc(DevView d) {
     const bool deep = x0 - 1 - UV_TX >= 2 && x0 + 2 * UV_TX <= d.L - 2 && uy0 - 1 - UV_TY >= 2 && uy0 + 2 * UV_TY <= d.M - 2
                       && uy0 - 1 - UV_TY + d.joff >= 2 && uy0 + 2 * UV_TY + d.joff <= d.Mg - 2;
     const bool wr_d2h = !(d.lean_d2h && deep);
-    if (interior) body_mont_visc<NL, true, LEITH>(d, x0, y0, wr_d2h, (double (*)[MV_LDY][MV_LDX])s_rv, (double (*)[MV_LDY][MV_LDX])s_dv, s_hh);
-    else body_mont_visc<NL, false, LEITH>(d, x0, y0, wr_d2h, (double (*)[MV_LDY][MV_LDX])s_rv, (double (*)[MV_LDY][MV_LDX])s_dv, s_hh);
+    const bool wr_prod = !(d.zero_visc && deep);              // zero viscosity: interior workgroups of k_uv_fused skip the term
+    if (interior) body_mont_visc<NL, true, LEITH>(d, x0, y0, wr_d2h, wr_prod, (double (*)[MV_LDY][MV_LDX])s_rv, (double (*)[MV_LDY][MV_LDX])s_dv, s_hh);
+    else body_mont_visc<NL, false, LEITH>(d, x0, y0, wr_d2h, wr_prod, (double (*)[MV_LDY][MV_LDX])s_rv, (double (*)[MV_LDY][MV_LDX])s_dv, s_hh);
 }
 static inline dim3 mont_visc_grid(const DevView &d) { return dim3(TileMap(d, MV_TX, MV_TY).blocks(), 1, 1); }
 
@@ -616,7 +622,7 @@ template <bool XDIR, bool PROD, bool STORE, class C, class SH>
 __device__ __forceinline__ double uv_core(const C &c, const DevView &d, int ilay, double gene, double ramp,
                                           double ctim, int copy_hist, const UVio &io,
                                           double q0, double qb, double qa, double qd, const SH &sh,
-                                          bool do_store = true, const double *pre = nullptr) {
+                                          bool do_store = true, const double *pre = nullptr, bool zv = false) {
     const int ipnt = c.ipnt;
     // u: cb = W(5), ca = N(3);   v: cb = S(7), ca = E(1)
     const int cb = XDIR ? c.template nb<5>() : c.template nb<7>();
@@ -660,6 +666,25 @@ __device__ __forceinline__ double uv_core(const C &c, const DevView &d, int ilay
                                                                + LL(d.vv4, ca, ilay) - LL(d.vv4, ipnt, ilay)) * i__h;
         else      rhsi = rhsi - d.svis * i_dl * (LL(d.vv4, ca, ilay) - LL(d.vv4, ipnt, ilay)
                                                 - LL(d.uu4, ipnt, ilay) + LL(d.uu4, cb, ilay)) * i__h;
+    } else if (PROD && zv) {
+        // v_cc = v_ll = +0 everywhere: both differences are +-0, so rhsi +- them is rhsi itself unless
+        // rhsi is an exact zero — and (+0) + (+-0) -+ (+-0) is +0 whatever the signs, so only rhsi = -0
+        // can change (to +0).  Those lanes rebuild dive, rvor at the three cells from the (old) u, v with
+        // the interior form of update_mont (:2388-2389, :2435-2436; masks 1) — all others skip the term.
+        if (rhsi == 0.0 && __builtin_signbit(rhsi)) {
+            const int oE = c.template nb<1>() - ipnt, oN = c.template nb<3>() - ipnt,
+                      oW = c.template nb<5>() - ipnt, oS = c.template nb<7>() - ipnt;
+            auto dive_at = [&](int x) {
+                return (LL(d.u, x + oE, ilay) - LL(d.u, x, ilay) + LL(d.v, x + oN, ilay) - LL(d.v, x, ilay)) * d.i_dl;
+            };
+            auto rvor_at = [&](int x) {
+                return (LL(d.v, x, ilay) - LL(d.v, x + oW, ilay) - LL(d.u, x, ilay) + LL(d.u, x + oS, ilay)) * d.i_dl * 1.0;
+            };
+            const double p0 = 0.0 * dive_at(ipnt), pb = 0.0 * dive_at(cb);
+            const double l0 = 0.0 * rvor_at(ipnt), la = 0.0 * rvor_at(ca);
+            if (XDIR) rhsi = rhsi + (p0 - pb) * i_dl - (la - l0) * i_dl;
+            else      rhsi = rhsi + (p0 - pb) * i_dl + (la - l0) * i_dl;
+        }
     } else if (PROD) {       // products staged by k_mont_visc: pcd = v_cc*dive, qlr = v_ll*rvor
         const double p0 = sh.pcd_s(), pb = sh.pcd_b();
         const double l0 = sh.qlr_s(), la = sh.qlr_a();
@@ -748,7 +773,7 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_update_uv(DevView d, int ilay_on
 template <bool FIRST_X, bool PROD, bool STORE, bool INT, class SH>
 __device__ __forceinline__ double uv_first_eval(const DevView &d, const CellDenseT<INT> &c, int ilay, double gene,
                                                 double ramp, double ctim, const SH &sh, bool do_store = true,
-                                                const double *pre = nullptr) {
+                                                const double *pre = nullptr, bool zv = false) {
     const int ipnt = c.ipnt;
     const int cb = FIRST_X ? c.template nb<5>() : c.template nb<7>();
     const int ca = FIRST_X ? c.template nb<3>() : c.template nb<1>();
@@ -758,7 +783,7 @@ __device__ __forceinline__ double uv_first_eval(const DevView &d, const CellDens
     const UVio io{FIRST_X ? d.u : d.v, FIRST_X ? d.u_alt : d.v_alt, FIRST_X ? d.h_u : d.h_v,
                   dm[0], dm[1], dm[2], dm[3]};
     if (pre) return uv_core<FIRST_X, PROD, STORE>(c, d, ilay, gene, ramp, ctim, 0, io, pre[1], pre[2], pre[3], pre[4],
-                                                  sh, do_store, pre);
+                                                  sh, do_store, pre, zv);
     return uv_core<FIRST_X, PROD, STORE>(c, d, ilay, gene, ramp, ctim, 0, io, LL(hq, ipnt, ilay),
                                          LL(hq, cb, ilay), LL(hq, ca, ilay), LL(hq, cd, ilay), sh, do_store);
 }
@@ -801,7 +826,7 @@ __device__ __forceinline__ void uv_pre_load(const DevView &d, const CellDenseT<t
     if (gene != 0.0) { pre[5] = LL(dm[0], ipnt, ilay); pre[6] = LL(dm[1], ipnt, ilay); pre[7] = LL(dm[2], ipnt, ilay); }
 }
 
-template <bool FIRST_X>
+template <bool FIRST_X, bool ZV>
 __device__ __forceinline__ void body_uv_fused_staged(const DevView &d, int x0, int y0, int ilay, double gene,
                                                      double ramp, double ctim, double (*s_h)[UV_LDX], UVstage *s_f,
                                                      double (*s_hl)[UV_HLDX]) {
@@ -812,7 +837,9 @@ __device__ __forceinline__ void body_uv_fused_staged(const DevView &d, int x0, i
     constexpr int NST = UV_SROWS * (UV_TX + 2), NIT = (NST + UV_BLOCK - 1) / UV_BLOCK;
     const long long lay = d.n1 * (long long)(ilay - 1);
     // ---- phase A loads: stage elements, outer hlay ring, first update of own cells and of the ring cell
-    const double *src[5] = {d.mont, d.pvor, d.pcd, d.qlr, d.hlay};
+    // ZV (zero viscosity): pcd, qlr are neither staged nor read
+    constexpr int NF = ZV ? 2 : 4;
+    const double *src[5] = {d.mont, d.pvor, ZV ? d.hlay : d.pcd, ZV ? d.hlay : d.qlr, d.hlay};
     double fv[NIT][5];
     int frr[NIT], fcc[NIT];
 #pragma unroll
@@ -822,7 +849,7 @@ __device__ __forceinline__ void body_uv_fused_staged(const DevView &d, int x0, i
         frr[k] = idc / (UV_TX + 2); fcc[k] = idc - frr[k] * (UV_TX + 2);
         const long long ip = (long long)(x0 - 1 + fcc[k]) + (long long)(y0 - 2 + frr[k]) * d.L + lay;
 #pragma unroll
-        for (int f = 0; f < 5; ++f) fv[k][f] = src[f][ip];
+        for (int f = 0; f < 5; ++f) if (f >= NF && f < 4) fv[k][f] = 0.0; else fv[k][f] = src[f][ip];
     }
     // outer ring of the hlay stage without its corners: d2hy needs the rows y0-2 and y0+TY+1,
     // d2hx the columns x0-2 and x0+TX+1
@@ -857,7 +884,7 @@ __device__ __forceinline__ void body_uv_fused_staged(const DevView &d, int x0, i
     for (int k = 0; k < NIT; ++k) {
         if (tid + k * UV_BLOCK < NST) {
 #pragma unroll
-            for (int f = 0; f < 4; ++f) s_f[f][frr[k]][fcc[k]] = fv[k][f];
+            for (int f = 0; f < NF; ++f) s_f[f][frr[k]][fcc[k]] = fv[k][f];
             s_hl[frr[k] + 1][fcc[k] + 1] = fv[k][4];
         }
     }
@@ -873,11 +900,11 @@ __device__ __forceinline__ void body_uv_fused_staged(const DevView &d, int x0, i
     for (int q = 0; q < UV_Q; ++q) {
         const int r = wy + UV_WAVES * q;
         const ShLds<FIRST_X> sh{s_f, s_hl, r + 1, lx + 1, d.ocrp, hs2};
-        s_h[r + ROFF][lx + COFF] = uv_first_eval<FIRST_X, true, true, true>(d, c[q], ilay, gene, ramp, ctim, sh, wr[q], pre[q]);
+        s_h[r + ROFF][lx + COFF] = uv_first_eval<FIRST_X, true, true, true>(d, c[q], ilay, gene, ramp, ctim, sh, wr[q], pre[q], ZV);
     }
     if (rr1 >= 0) {
         const ShLds<FIRST_X> sh{s_f, s_hl, rb - (y0 - 1), ra - (x0 - 1), d.ocrp, hs2};
-        s_h[rr1][cc1] = uv_first_eval<FIRST_X, true, false, true>(d, hc, ilay, gene, ramp, ctim, sh, true, preR);
+        s_h[rr1][cc1] = uv_first_eval<FIRST_X, true, false, true>(d, hc, ilay, gene, ramp, ctim, sh, true, preR, ZV);
     }
     __syncthreads();
     // ---- second component, transport of the first from LDS
@@ -895,7 +922,7 @@ __device__ __forceinline__ void body_uv_fused_staged(const DevView &d, int x0, i
             q0 = s_h[r][lx + 1]; qb = s_h[r][lx]; qa = s_h[r + 1][lx + 1]; qd = s_h[r + 1][lx];
         }
         const ShLds<!FIRST_X> sh{s_f, s_hl, r + 1, lx + 1, d.ocrp, hs2};
-        uv_core<!FIRST_X, true, true>(c[q], d, ilay, gene, ramp, ctim, 0, io, q0, qb, qa, qd, sh, true, pre2[q]);
+        uv_core<!FIRST_X, true, true>(c[q], d, ilay, gene, ramp, ctim, 0, io, q0, qb, qa, qd, sh, true, pre2[q], ZV);
     }
 }
 
@@ -969,10 +996,11 @@ __device__ __forceinline__ void body_uv_fused(const DevView &d, int x0, int y0, 
     }
 }
 
-template <bool FIRST_X, bool PROD>
+// ZV (with PROD): v_cc = v_ll = +0 everywhere — interior workgroups drop the viscous products
+template <bool FIRST_X, bool PROD, bool ZV = false>
 __global__ __launch_bounds__(UV_BLOCK) void k_uv_fused(DevView d, double gene, double ramp, double ctim) {
     __shared__ double s_h[UV_TY + 1][UV_LDX];
-    __shared__ UVstage s_f[PROD ? 4 : 1];
+    __shared__ UVstage s_f[PROD ? (ZV ? 2 : 4) : 1];
     __shared__ double s_hl[PROD ? UV_HROWS : 1][UV_HLDX];
     const TileMap tm(d, UV_TX, UV_TY);
     int ty, ch;
@@ -981,7 +1009,7 @@ __global__ __launch_bounds__(UV_BLOCK) void k_uv_fused(DevView d, double gene, d
     const int ilay = blockIdx.y + 1;
     const bool interior = x0 - 1 >= 2 && x0 + UV_TX <= d.L - 2 && y0 - 1 >= 2 && y0 + UV_TY <= d.M - 2
                           && y0 - 1 + d.joff >= 2 && y0 + UV_TY + d.joff <= d.Mg - 2;
-    if (interior && PROD) body_uv_fused_staged<FIRST_X>(d, x0, y0, ilay, gene, ramp, ctim, s_h, s_f, s_hl);
+    if (interior && PROD) body_uv_fused_staged<FIRST_X, ZV>(d, x0, y0, ilay, gene, ramp, ctim, s_h, s_f, s_hl);
     else if (interior) body_uv_fused<FIRST_X, PROD, true>(d, x0, y0, ilay, gene, ramp, ctim, s_h);
     else body_uv_fused<FIRST_X, PROD, false>(d, x0, y0, ilay, gene, ramp, ctim, s_h);
 }

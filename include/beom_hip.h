@@ -170,6 +170,8 @@ int beom_unpack_rows(beom_handle h, int jlo, int nrows, const void *device_buffe
  *      from step 4 on, forms the products of the standing v_cc, v_ll instead (rvor, dive again
  *      only with "keep_diag"); with n_3d > 1 the refresh steps also store v_cc, v_ll and the
  *      steps in between use that standing-viscosity form.
+ *  "lean_d2h", "lean_visc" (default 1): the fused pair re-derives d2hx, d2hy in the momentum sweep,
+ *      and drops the viscous products altogether when v_cc = v_ll = +0 and never refreshed.
  *  "fuse_uv" (default 1): update_u and update_v of a step run as ONE sweep.
  *  "fuse": sets both.  0 = always five separate sweeps.
  * Returns -3 for an unknown name. */

@@ -171,7 +171,7 @@ def test_restart_split_equals_single_run():
         x.close()
 
 
-@pytest.mark.parametrize("case", ["closed", "sill_ocrp"])
+@pytest.mark.parametrize("case", ["closed", "sill_ocrp", "beach_zero_visc", "soliton_zero_visc"])
 def test_lean_thickness_curvature_matches_oracle(case):
     """Production pair of fused sweeps on a frame with DEEP tiles (>= 3 tiles away from every
     edge): k_mont_visc stores d2hx/d2hy only around non-interior tiles, k_uv_fused re-derives
@@ -181,11 +181,16 @@ def test_lean_thickness_curvature_matches_oracle(case):
     from beom_amd.grid import read_input_data
     if case == "closed":
         p, files = I.case_headline(330, 75, 2)
+    elif case == "beach_zero_visc":        # dvis = bvis = 0: the fused pair also drops the (+-0) viscous products
+        p, files = I.case_carrier_beach(lm=330, mm=75, nlay=2, dt_s=0.08)
+    elif case == "soliton_zero_visc":      # ... at rest far from the soliton: many exactly-zero right-hand sides
+        p, files = I.case_soliton(lm=331, mm=75, dt_s=5.0)
     else:
         p, files = I.case_sill_exchange3d(lm=330, mm=75, nlay=3, dt_s=0.01, npts=5, sill_halfwidth=20.0)
     f = read_input_data(p, files=files)
     lean, full = capi.Engine(f), capi.Engine(f)
     full.set_option("lean_d2h", 0)
+    full.set_option("lean_visc", 0)
     assert lean.is_dense
     o = oracle_lib.Oracle(f)
     n = 14
@@ -195,6 +200,8 @@ def test_lean_thickness_curvature_matches_oracle(case):
     for k in PROGNOSTIC:
         assert same(sl[k], o.state()[k]), (case, k, maxrel(sl[k], o.state()[k]))
         assert same(sf[k], sl[k]), (case, k)
+    for k in ("hlay", "u", "v", "h_u", "h_v"):            # the sign of zero too
+        assert same_bits(sl[k], o.state()[k]), (case, k, "sign of zero")
     cl, cf = lean.download_scratch(), full.download_scratch()
     L = p.lm + 1
     ip = 200 + (40 - 1) * L                      # cell (200, 40): tile x0 = 193, y0 = 33 is deep
