@@ -229,11 +229,14 @@ def _big_cases():
         "sill_ocrp_nudg_4l": lambda: I.case_sill_exchange3d(lm=133, mm=41, nlay=4, dt_s=0.01, npts=5,
                                                             sill_halfwidth=6.0),
         "stommel_wind_drag": lambda: I.case_stommel(lm=200, mm=30, dl=50.0e3, dt_s=0.2),
+        # 8 layers (BASELINE config 5's layer count): outcropping beach, and a closed basin with Leith viscosity
+        "beach_ocrp_8l": lambda: I.case_carrier_beach(lm=150, mm=37, nlay=8, dt_s=0.08),
+        "closed_8l": lambda: I.case_headline(150, 37, 8),
     }
 
 
 @pytest.mark.parametrize("case", ["closed_3l", "closed_3l_biharm", "soliton_xper", "jet_xyper_2l",
-                                  "sill_ocrp_nudg_4l", "stommel_wind_drag"])
+                                  "sill_ocrp_nudg_4l", "stommel_wind_drag", "beach_ocrp_8l", "closed_8l"])
 def test_dense_interior_waves_match_oracle_and_gather(case):
     """Grids wide enough (L >= 130) that most waves take the INTERIOR specialisation of
     CellDenseT; the dense path, the gather path and the oracle must agree bitwise."""
