@@ -34,6 +34,23 @@ class BeomParams(C.Structure):
     )
 
 
+STATICS_NAMES = ("fcor", "h_th", "h_to", "nudg", "fnud", "hdot", "tide", "bodf", "taus")
+
+
+class BeomStatics(C.Structure):
+    """struct beom_statics of include/beom_hip.h."""
+    _fields_ = [(n, C.POINTER(C.c_double)) for n in STATICS_NAMES]
+
+
+class BeomState(C.Structure):
+    """struct beom_state of include/beom_hip.h."""
+    _fields_ = [(n, C.POINTER(C.c_double)) for n in ("hlay", "u", "v", "h_u", "h_v", "rs_h", "dmdx", "dmdy",
+                                                     "v_cc", "v_ll", "tt3d", "tb3d", "tu3d")]
+
+
+XCHG_PEER, XCHG_RCCL, XCHG_RING1 = 0, 1, 0x100
+
+
 def make_params_struct(p: Params, f: Optional[Fields] = None, variant: int = 0,
                        dense_hint: int = 1, slab_row0: int = 0, slab_mm: int = 0) -> BeomParams:
     s = BeomParams()
@@ -78,7 +95,7 @@ def source_hash() -> str:
     import hashlib
     csrc = os.path.join(_HERE, "csrc")
     h = hashlib.sha1()
-    for fn in ("beom_engine.hip", "beom_multi.hip", "beom_dev.h", "beom_kernels.h",
+    for fn in ("beom_engine.hip", "beom_multi.hip", "beom_dev.h", "beom_kernels.h", "beom_dense_host.h",
                os.path.join("..", "..", "include", "beom_hip.h")):
         with open(os.path.join(csrc, fn), "rb") as f:
             h.update(f.read())
@@ -149,9 +166,23 @@ def load(path: Optional[str] = None) -> C.CDLL:
     lib.beom_multi_step.argtypes = [MH, ci, ci, cd, cd, cd, cd, ci, cp, ci]
     lib.beom_multi_sync.argtypes = [MH, cp, ci]
     lib.beom_multi_stats.argtypes = [MH, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+    lib.beom_multi_create_ex.argtypes = [C.POINTER(BeomParams), ci, C.POINTER(ci), ci, ipp, ipp] + [dpp] * 14 + [C.POINTER(MH), cp, ci]
+    lib.beom_multi_describe.argtypes = [MH] + [C.POINTER(ci)] * 5
+    lib.beom_multi_engine.argtypes = [MH, ci, C.POINTER(H)]
+    lib.beom_multi_profile_start.argtypes = [MH]
+    lib.beom_multi_profile_stop.argtypes = [MH, dpp, C.POINTER(ci), cp, ci]
+    lib.beom_rccl_unique_id.argtypes = [C.c_void_p, cp, ci]
+    lib.beom_rccl_version.argtypes = [cp, ci]
+    lib.beom_multi_window.argtypes = [C.POINTER(BeomParams), ci, ci, ci] + [C.POINTER(ci)] * 4
+    lib.beom_multi_create_local.argtypes = [C.POINTER(BeomParams), ci, ci, ci, ci, ci, C.c_void_p,
+                                            C.POINTER(BeomStatics), C.POINTER(BeomStatics), C.POINTER(MH), cp, ci]
+    lib.beom_multi_upload_local.argtypes = [MH, C.POINTER(BeomState), C.POINTER(BeomState), cp, ci]
+    lib.beom_multi_download_local.argtypes = [MH, C.POINTER(BeomState), C.POINTER(BeomState), cp, ci]
     for name in ("beom_multi_create", "beom_multi_destroy", "beom_multi_count", "beom_multi_band",
                  "beom_multi_upload_state", "beom_multi_download_state", "beom_multi_step", "beom_multi_sync",
-                 "beom_multi_stats"):
+                 "beom_multi_stats", "beom_multi_create_ex", "beom_multi_describe", "beom_multi_engine",
+                 "beom_multi_profile_start", "beom_multi_profile_stop", "beom_rccl_unique_id", "beom_rccl_version",
+                 "beom_multi_window", "beom_multi_create_local", "beom_multi_upload_local", "beom_multi_download_local"):
         getattr(lib, name).restype = ci
     for name in ("beom_device_count", "beom_create", "beom_destroy", "beom_upload_state",
                  "beom_download_state", "beom_download_scratch", "beom_step", "beom_sync",
@@ -177,7 +208,9 @@ EXPORTS = ("beom_abi_version", "beom_device_count", "beom_create", "beom_destroy
            "beom_set_open_boundaries",
            "beom_multi_create", "beom_multi_destroy", "beom_multi_count", "beom_multi_band",
            "beom_multi_upload_state", "beom_multi_download_state", "beom_multi_step", "beom_multi_sync",
-           "beom_multi_stats")
+           "beom_multi_stats", "beom_multi_create_ex", "beom_multi_describe", "beom_multi_engine",
+           "beom_multi_profile_start", "beom_multi_profile_stop", "beom_rccl_unique_id", "beom_rccl_version",
+           "beom_multi_window", "beom_multi_create_local", "beom_multi_upload_local", "beom_multi_download_local")
 
 STATE_NAMES = ("hlay", "u", "v", "h_u", "h_v", "rs_h", "dmdx", "dmdy", "v_cc", "v_ll",
                "tt3d", "tb3d", "tu3d")
@@ -353,7 +386,8 @@ class MultiEngine:
     exchange inside the library) — what the Fortran host uses with BEOM_NGPU > 1.  `devices` may
     name a device more than once (tests: three bands on the one GPU of the box)."""
 
-    def __init__(self, f: Fields, devices=(0,), variant: int = 0, upload: bool = True):
+    def __init__(self, f: Fields, devices=(0,), variant: int = 0, upload: bool = True,
+                 transport: int = XCHG_PEER, ring1: bool = False):
         self.lib = load()
         self.f, self.p = f, f.p
         self.prm = make_params_struct(f.p, f, variant, 1, 0, 0)
@@ -361,8 +395,8 @@ class MultiEngine:
         self.h = C.c_void_p()
         dev = (C.c_int * len(devices))(*devices)
         opt = lambda k: _dp(getattr(f, k)) if f.has.get(k, True) else None
-        rc = self.lib.beom_multi_create(
-            C.byref(self.prm), len(devices), dev, _ip(f.neig), _ip(f.subc),
+        rc = self.lib.beom_multi_create_ex(
+            C.byref(self.prm), len(devices), dev, transport | (XCHG_RING1 if ring1 else 0), _ip(f.neig), _ip(f.subc),
             _dp(f.mk_u), _dp(f.mk_v), _dp(f.mk_n), _dp(f.mkpe), _dp(f.mkpi),
             _dp(f.fcor), _dp(f.h_th), _dp(f.h_to), _dp(f.nudg), _dp(f.fnud),
             opt("hdot"), opt("tide"), opt("bodf"), _dp(f.taus),
@@ -417,3 +451,112 @@ class MultiEngine:
         a, b = C.c_longlong(), C.c_longlong()
         self.lib.beom_multi_stats(self.h, C.byref(a), C.byref(b))
         return {"split": a.value, "plain": b.value}
+
+    def describe(self) -> dict:
+        v = [C.c_int() for _ in range(5)]
+        self._check(self.lib.beom_multi_describe(self.h, *[C.byref(x) for x in v]))
+        d = dict(zip(("bands_total", "bands_local", "transport", "ring", "rccl_version"), (x.value for x in v)))
+        d["transport"] = {XCHG_PEER: "hipMemcpyPeerAsync", XCHG_RCCL: "RCCL ncclSend/ncclRecv"}.get(d["transport"], "?")
+        return d
+
+    def profile_start(self):
+        self._check(self.lib.beom_multi_profile_start(self.h))
+
+    def profile_stop(self):
+        ms = (C.c_double * 8)()
+        nl = (C.c_int * 8)()
+        self._check(self.lib.beom_multi_profile_stop(self.h, ms, nl, self._err, ERRLEN))
+        return list(ms)[:7], list(nl)[:7]
+
+    def profile_steps(self, tstp_first: int, nsteps: int, tres: float = 0.0):
+        self.profile_start()
+        self.step(tstp_first, nsteps, tres, sync=False)
+        return self.profile_stop()
+
+    def set_option(self, name: str, value: int):
+        """Forwarded to every local band (and the companion frame of a ring)."""
+        for k in range(-1, self.count):
+            h = C.c_void_p()
+            self._check(self.lib.beom_multi_engine(self.h, k, C.byref(h)))
+            if h.value:
+                self._check(self.lib.beom_set_option(h, name.encode(), int(value)))
+
+
+def rccl_unique_id() -> bytes:
+    """128 bytes of ncclGetUniqueId (one rank calls it, every rank of the job gets the bytes)."""
+    lib = load()
+    buf = C.create_string_buffer(128)
+    err = C.create_string_buffer(ERRLEN + 1)
+    rc = lib.beom_rccl_unique_id(buf, err, ERRLEN)
+    if rc != 0:
+        raise BeomError("beom_rccl_unique_id %d: %s" % (rc, err.value.decode(errors="replace")))
+    return buf.raw
+
+
+def multi_window(p: Params, nb: int, band: int, yper: bool) -> dict:
+    """Rows of band `band` of `nb`: owned global rows own0..own1 and the ghost rows on either side."""
+    lib = load()
+    prm = make_params_struct(p)
+    v = [C.c_int() for _ in range(4)]
+    rc = lib.beom_multi_window(C.byref(prm), nb, band, int(bool(yper)), *[C.byref(x) for x in v])
+    if rc != 0:
+        raise BeomError("beom_multi_window %d" % rc)
+    return dict(zip(("own0", "own1", "ghost_s", "ghost_n"), (x.value for x in v)))
+
+
+class BandEngine(MultiEngine):
+    """beom_multi_create_local: ONE band of a frame cut over `nb` processes, built from that band's window
+    only (bench.py under torchrun; exchange over RCCL).  `f` = the window's Fields (rows: south ghosts,
+    owned rows, north ghosts — beom_amd.slab.build_window), `p_global` the global frame's parameters,
+    `orphan` = Fields of row mm+1 (band 0 of a frame periodic in y)."""
+
+    def __init__(self, f: Fields, p_global: Params, nb: int, band: int, device: int = 0, variant: int = 0,
+                 rccl_id: Optional[bytes] = None, orphan: Optional[Fields] = None, upload: bool = True):
+        self.lib = load()
+        self.f, self.p, self.pg = f, f.p, p_global
+        self.orphan = orphan
+        self.prm = make_params_struct(p_global, f, variant, 1, 0, 0)
+        self._err = C.create_string_buffer(ERRLEN + 1)
+        self.h = C.c_void_p()
+        idbuf = C.create_string_buffer(rccl_id, 128) if rccl_id is not None else None
+        st = self._statics(f)
+        so = self._statics(orphan) if orphan is not None else None
+        rc = self.lib.beom_multi_create_local(
+            C.byref(self.prm), nb, band, device, int(float(p_global.xper) > 0.5), int(float(p_global.yper) > 0.5),
+            idbuf, C.byref(st), C.byref(so) if so is not None else None, C.byref(self.h), self._err, ERRLEN)
+        self._check(rc)
+        if upload:
+            self.upload()
+
+    @staticmethod
+    def _statics(f: Fields) -> BeomStatics:
+        s = BeomStatics()
+        for k in STATICS_NAMES:
+            present = f.has.get(k, True) if k in ("hdot", "tide", "bodf") else True
+            setattr(s, k, _dp(getattr(f, k)) if present else None)
+        return s
+
+    @staticmethod
+    def _state(arrays: dict) -> BeomState:
+        s = BeomState()
+        for k in STATE_NAMES:
+            setattr(s, k, _dp(arrays.get(k)))
+        return s
+
+    def upload(self, **arrays):
+        src = arrays or {k: getattr(self.f, k) for k in STATE_NAMES}
+        sw = self._state(src)
+        so = self._state({k: getattr(self.orphan, k) for k in STATE_NAMES}) if self.orphan is not None else None
+        self._check(self.lib.beom_multi_upload_local(self.h, C.byref(sw), C.byref(so) if so is not None else None,
+                                                     self._err, ERRLEN))
+
+    def download(self, names=STATE_NAMES, orphan: bool = False) -> dict:
+        out = {k: np.zeros_like(getattr(self.f, k)) for k in names}
+        sw = self._state(out)
+        oo, so = None, None
+        if orphan and self.orphan is not None:
+            oo = {k: np.zeros_like(getattr(self.orphan, k)) for k in names}
+            so = self._state(oo)
+        self._check(self.lib.beom_multi_download_local(self.h, C.byref(sw), C.byref(so) if so is not None else None,
+                                                       self._err, ERRLEN))
+        return (out, oo) if orphan else out

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "beom_kernels.h"
+#include "beom_dense_host.h"
 
 namespace {
 
@@ -91,53 +92,10 @@ bool any_nonzero(const double *a, size_t n) {
     return false;
 }
 
-struct HostNb {   // host twin of CellDenseT::at
-    int L, M, xper, ywrap;
-    int at(int a, int b) const {
-        if (xper) { if (a == 0) a = L - 1; else if (a == L) a = 1; }
-        if (ywrap) { if (b == 0) b = M - 1; else if (b == M) b = 1; }
-        return (a >= 1 && a <= L && b >= 1 && b <= M) ? (a + (b - 1) * L) : 0;
-    }
-};
-
-// SURVEY App. A, generalised to a j-slab window: local rows 1..M are global rows
-// joff+1..joff+M of an Mg-row frame.  Neighbours are local indices (0 outside the window);
-// masks and subc(:,2) are those of the global frame.
-bool verify_dense(int L, int M, int joff, int Mg, int slab, int xper, int yper, long long ndeg,
-                  const int32_t *neig, const int32_t *subc, const double *mk_u, const double *mk_v,
-                  const double *mk_n, const double *mkpe, const double *mkpi) {
-    if (ndeg != (long long)L * M) return false;
-    const HostNb nb{L, M, xper, (yper && !slab) ? 1 : 0};
-    static const int di[8] = {1, 1, 0, -1, -1, -1, 0, 1};
-    static const int dj[8] = {0, 1, 1, 1, 0, -1, -1, -1};
-    const long long n1 = ndeg + 1;
-    for (int j = 1; j <= M; ++j) {
-        const int jg = j + joff;
-        for (int i = 1; i <= L; ++i) {
-            const long long ip = i + (long long)(j - 1) * L;
-            if (subc[ip] != i || subc[ip + n1] != jg) return false;
-            for (int k = 0; k < 8; ++k)
-                if (neig[k + 8 * ip] != nb.at(i + di[k], j + dj[k])) return false;
-            // mask predicates of CellDenseT (private_mod.f95:701-714 + periodic :621,627,649,655,676)
-            const bool in = i <= L - 1 && jg <= Mg - 1;
-            const double en = in ? 1.0 : 0.0;
-            const double eu = (in && (i >= 2 || xper)) ? 1.0 : 0.0;
-            const double ev = (in && (jg >= 2 || yper)) ? 1.0 : 0.0;
-            const double ep = (in && (i >= 2 || xper) && (jg >= 2 || yper)) ? 1.0 : 0.0;
-            if (mk_n[ip] != en || mk_u[ip] != eu || mk_v[ip] != ev || mkpe[ip] != ep || mkpi[ip] != 1.0) return false;
-        }
-    }
-    return true;
-}
-
 }  // namespace
 
 extern "C" {
 
-#ifndef BEOM_SRC_HASH
-#define BEOM_SRC_HASH "unknown"
-#endif
-const char *beom_source_hash(void) { return BEOM_SRC_HASH; }
 int beom_abi_version(void) { return BEOM_ABI_VERSION; }
 
 int beom_device_count(char *errm, int errm_len) {
@@ -164,7 +122,18 @@ int beom_create(const beom_params *prm, int device, const int32_t *neig, const i
     beom_engine *E = new beom_engine();
     E->P = *prm;
     E->device = device;
-    HIP_TRY(hipStreamCreateWithFlags(&E->own_stream, hipStreamNonBlocking));
+    // from here on every failure releases the handle (its stream and device arrays) on the way out
+#define HIP_TRY_E(expr)                                                                     \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            set_err(errm, errm_len, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                    __FILE__, __LINE__);                                                    \
+            beom_destroy(E);                                                                \
+            return -100 - (int)e_;                                                          \
+        }                                                                                   \
+    } while (0)
+    HIP_TRY_E(hipStreamCreateWithFlags(&E->own_stream, hipStreamNonBlocking));
     E->stream = E->own_stream;
     DevView &d = E->d;
     const size_t n1 = (size_t)prm->ndeg + 1, nl = (size_t)prm->nlay;
@@ -190,13 +159,13 @@ int beom_create(const beom_params *prm, int device, const int32_t *neig, const i
     d.slab = prm->slab_mm > 0 ? 1 : 0;
     d.joff = d.slab ? prm->slab_row0 : 0;
     d.Mg = d.slab ? prm->slab_mm + 1 : d.M;
-    if (d.slab && (d.joff < 0 || d.joff + d.M > d.Mg)) { set_err(errm, errm_len, "beom_create: slab rows outside the global frame"); delete E; return -3; }
+    if (d.slab && (d.joff < 0 || d.joff + d.M > d.Mg)) { set_err(errm, errm_len, "beom_create: slab rows outside the global frame"); beom_destroy(E); return -3; }
     E->dense = false;
     if (prm->dense_hint && (long long)prm->ndeg == (long long)d.L * d.M) {
         for (int xp = 0; xp < 2 && !E->dense; ++xp)
             for (int yp = 0; yp < 2 && !E->dense; ++yp) {
                 if (d.slab && yp) continue;      // a slab of a y-periodic frame gets its wrap from the exchange, not from neig
-                if (verify_dense(d.L, d.M, d.joff, d.Mg, d.slab, xp, yp, prm->ndeg, neig, subc, mk_u, mk_v, mk_n, mkpe, mkpi)) {
+                if (beom_dense::verify(d.L, d.M, d.joff, d.Mg, d.slab, xp, yp, prm->ndeg, neig, subc, mk_u, mk_v, mk_n, mkpe, mkpi)) {
                     E->dense = true; d.xper = xp; d.yper = yp;
                 }
             }
@@ -269,15 +238,16 @@ int beom_create(const beom_params *prm, int device, const int32_t *neig, const i
     // initialize_variables: v_cc = v_ll = bvis everywhere, sentinel included (:276-277)
     if (prm->bvis != 0.0) {
         std::vector<double> b(nl * n1, prm->bvis);
-        HIP_TRY(hipMemcpyAsync(d.v_cc, b.data(), b.size() * sizeof(double), hipMemcpyHostToDevice, E->stream));
-        HIP_TRY(hipMemcpyAsync(d.v_ll, b.data(), b.size() * sizeof(double), hipMemcpyHostToDevice, E->stream));
-        HIP_TRY(hipStreamSynchronize(E->stream));
+        HIP_TRY_E(hipMemcpyAsync(d.v_cc, b.data(), b.size() * sizeof(double), hipMemcpyHostToDevice, E->stream));
+        HIP_TRY_E(hipMemcpyAsync(d.v_ll, b.data(), b.size() * sizeof(double), hipMemcpyHostToDevice, E->stream));
+        HIP_TRY_E(hipStreamSynchronize(E->stream));
     }
     const unsigned gx = (unsigned)((prm->ndeg + BEOM_BLOCK - 1) / BEOM_BLOCK);
     const unsigned gx0 = (unsigned)((prm->ndeg + 1 + BEOM_BLOCK - 1) / BEOM_BLOCK);
     E->grid_cells_layers_flat = dim3(gx, (unsigned)prm->nlay, 1);
     E->grid_cells0 = dim3(gx0, 1, 1);
-    HIP_TRY(hipStreamSynchronize(E->stream));
+    HIP_TRY_E(hipStreamSynchronize(E->stream));
+#undef HIP_TRY_E
     *out = E;
     return 0;
 }
@@ -534,13 +504,15 @@ extern "C" {
 
 #define NEED(E) do { if (!(E)) return -1; if (hipSetDevice((E)->device) != hipSuccess) return -9; } while (0)
 
-int beom_update_h(beom_handle E, double gene, double ramp, double ctim) { NEED(E); launch_h(E, gene, ramp, ctim); return 0; }
-int beom_update_mont_rvor_pvor_dive_kine(beom_handle E, int ilay) { NEED(E); if (ilay < 0 || ilay > E->d.nlay) return -3; launch_mont(E, ilay); return 0; }
-int beom_update_viscosity(beom_handle E, int ilay) { NEED(E); if (ilay < 0 || ilay > E->d.nlay) return -3; launch_visc(E, ilay); return 0; }
-int beom_update_u(beom_handle E, int ilay, double gene, double ramp, double ctim) { NEED(E); if (ilay < 0 || ilay > E->d.nlay) return -3; launch_uv<true>(E, ilay, gene, ramp, ctim); return 0; }
-int beom_update_v(beom_handle E, int ilay, double gene, double ramp, double ctim) { NEED(E); if (ilay < 0 || ilay > E->d.nlay) return -3; launch_uv<false>(E, ilay, gene, ramp, ctim); return 0; }
-int beom_rebuild_fluxes(beom_handle E) { NEED(E); launch_rebuild(E); return 0; }
-int beom_distribute_stress(beom_handle E) { NEED(E); launch_stress(E); return 0; }
+#define LAUNCHED() (hipGetLastError() == hipSuccess ? 0 : -10)
+int beom_update_h(beom_handle E, double gene, double ramp, double ctim) { NEED(E); launch_h(E, gene, ramp, ctim); return LAUNCHED(); }
+int beom_update_mont_rvor_pvor_dive_kine(beom_handle E, int ilay) { NEED(E); if (ilay < 0 || ilay > E->d.nlay) return -3; launch_mont(E, ilay); return LAUNCHED(); }
+int beom_update_viscosity(beom_handle E, int ilay) { NEED(E); if (ilay < 0 || ilay > E->d.nlay) return -3; launch_visc(E, ilay); return LAUNCHED(); }
+int beom_update_u(beom_handle E, int ilay, double gene, double ramp, double ctim) { NEED(E); if (ilay < 0 || ilay > E->d.nlay) return -3; launch_uv<true>(E, ilay, gene, ramp, ctim); return LAUNCHED(); }
+int beom_update_v(beom_handle E, int ilay, double gene, double ramp, double ctim) { NEED(E); if (ilay < 0 || ilay > E->d.nlay) return -3; launch_uv<false>(E, ilay, gene, ramp, ctim); return LAUNCHED(); }
+int beom_rebuild_fluxes(beom_handle E) { NEED(E); launch_rebuild(E); return LAUNCHED(); }
+int beom_distribute_stress(beom_handle E) { NEED(E); launch_stress(E); return LAUNCHED(); }
+#undef LAUNCHED
 
 }  // extern "C"
 
@@ -735,17 +707,19 @@ int beom_step_phase(beom_handle E, int tstp, double tres, double dtd8, double dt
 // rows [jlo, jlo+nrows) of hlay,u,v,h_u,h_v  ->  dbuf (device memory, 5*nlay*nrows*(lm+1) doubles)
 int beom_pack_rows(beom_handle E, int jlo, int nrows, void *dbuf) {
     if (!E || !dbuf || jlo < 1 || nrows < 1 || jlo + nrows - 1 > E->d.M) return -3;
+    if (hipSetDevice(E->device) != hipSuccess) return -9;
     const long long total = 5ll * E->d.nlay * nrows * E->d.L;
     hipLaunchKernelGGL((k_rows_copy<true>), dim3((unsigned)((total + BEOM_BLOCK - 1) / BEOM_BLOCK)), dim3(BEOM_BLOCK),
                        0, E->stream, E->d, jlo, nrows, (double *)dbuf);
-    return 0;
+    return hipGetLastError() == hipSuccess ? 0 : -10;
 }
 int beom_unpack_rows(beom_handle E, int jlo, int nrows, const void *dbuf) {
     if (!E || !dbuf || jlo < 1 || nrows < 1 || jlo + nrows - 1 > E->d.M) return -3;
+    if (hipSetDevice(E->device) != hipSuccess) return -9;
     const long long total = 5ll * E->d.nlay * nrows * E->d.L;
     hipLaunchKernelGGL((k_rows_copy<false>), dim3((unsigned)((total + BEOM_BLOCK - 1) / BEOM_BLOCK)), dim3(BEOM_BLOCK),
                        0, E->stream, E->d, jlo, nrows, (double *)dbuf);
-    return 0;
+    return hipGetLastError() == hipSuccess ? 0 : -10;
 }
 
 // Output preparation on the device: replaces the array work of write_array for

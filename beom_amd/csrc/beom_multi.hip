@@ -1,15 +1,27 @@
-// beom_multi.hip — one process, several GPUs: the j-slab decomposition of SURVEY.md §8(e) behind
-// the same C-ABI shape as the single-device handle, for hosts that stay single-process (the
-// Fortran host under main.f95; SURVEY §8(b) "Threading").  The reference has no counterpart
-// (OpenMP only).  Built only from the public entry points of include/beom_hip.h:
-//   * the frame (dense: ndeg = (lm+1)(mm+1)) is cut into bands of rows; every band becomes an
-//     ordinary slab handle (beom_params.slab_row0/slab_mm) on its own device, with G = 4 ghost
-//     rows per neighbour — the scheme of beom_amd/slab.py, which drives one process per GPU;
-//   * one exchange per time step of hlay,u,v,h_u,h_v: beom_pack_rows on the owner, a peer copy
-//     over xGMI (hipMemcpyPeerAsync) on the receiver's second stream, beom_unpack_rows there;
-//   * the exchange of step n overlaps phase 1 of step n+1 (beom_step_phase), as in slab.py.
+// beom_multi.hip — the j-slab decomposition of SURVEY.md §8(e) behind the C-ABI: a dense frame cut
+// into bands of rows, one band per GPU, ghost rows exchanged once per time step, the exchange of
+// step n overlapped with the interior rows of step n+1.  The reference has no counterpart (OpenMP
+// only).  Built only from the public entry points of include/beom_hip.h.
+//
+//   * every band is an ordinary slab handle (beom_params.slab_row0/slab_mm) with G = 4 ghost rows per
+//     neighbour; per step ONE exchange of hlay,u,v,h_u,h_v (beom_pack_rows -> transport ->
+//     beom_unpack_rows on the band's second stream), beom_step_phase 1/2 around it;
+//   * transports: peer copies between the bands of ONE process (hipMemcpyPeerAsync over xGMI), or RCCL
+//     (grouped ncclSend/ncclRecv; librccl is loaded at run time) — either all bands in one process
+//     (ncclCommInitAll) or ONE band per process (ncclCommInitRank: bench.py under torchrun);
+//   * two ways in: GLOBAL arrays that the library cuts (beom_multi_create: the Fortran host), or this
+//     band's WINDOW only (beom_multi_create_local: nothing of global size exists on any rank);
+//   * frames periodic in y: the bands form a ring over rows 1..mm (a band of a ring is a slab deep inside
+//     a taller fake frame: every mask is 1, the wrap comes from the exchange).  The orphan row mm+1
+//     keeps its slot in every array and output record (private_mod.f95:642-668: its E/W neighbours are
+//     cells of row 1, its S neighbours cells of row mm, nothing points to it) and is carried by a
+//     companion frame on band 0's device: rows 1..6, mm-3..mm and mm+1 as ONE small y-periodic frame,
+//     its first ten rows refreshed from band 0 before every step.
+// The K steps of one call run inside the library: no per-step host language in the loop.
 // No CPU fallback: every call needs its HIP devices.
 #include <hip/hip_runtime.h>
+
+#include <dlfcn.h>
 
 #include <cstdarg>
 #include <cstdio>
@@ -18,11 +30,14 @@
 #include <vector>
 
 #include "../../include/beom_hip.h"
+#include "beom_dense_host.h"
 
 namespace {
 
-constexpr int kGhost = 4;          // rows per neighbour; see beom_amd/slab.py for why 4 is enough
+constexpr int kGhost = 4;          // rows per neighbour; see DESIGN.md §5 for why 4 is enough
 constexpr int kFields = 5;         // hlay, u, v, h_u, h_v
+constexpr int kMiniLo = 6;         // rows 1..6 of a y-periodic frame that the companion frame carries
+constexpr int kFakePad = 8;        // a ring band is presented as rows 9.. of a frame 16 rows taller
 
 void m_err(char *errm, int len, const char *fmt, ...) {
     if (!errm || len <= 0) return;
@@ -43,48 +58,132 @@ void m_err(char *errm, int len, const char *fmt, ...) {
     } while (0)
 #define M_RC(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
 
+// ---- RCCL, bound at run time (one copy per process: PyTorch-ROCm ships librccl.so.1 too) --------
+typedef void *nccl_comm;
+struct nccl_uid { char internal[128]; };
+struct Rccl {
+    void *lib = nullptr;
+    int (*GetUniqueId)(nccl_uid *) = nullptr;
+    int (*CommInitRank)(nccl_comm *, int, nccl_uid, int) = nullptr;
+    int (*CommInitAll)(nccl_comm *, int, const int *) = nullptr;
+    int (*CommDestroy)(nccl_comm) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void *, size_t, int, int, nccl_comm, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, nccl_comm, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    int (*GetVersion)(int *) = nullptr;
+    bool load(char *errm, int errm_len) {
+        if (lib) return true;
+        const char *names[] = {getenv("BEOM_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *nm : names) {
+            if (!nm || !*nm) continue;
+            lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+            if (lib) break;
+        }
+        if (!lib) { m_err(errm, errm_len, "RCCL transport: librccl.so.1 not found (%s)", dlerror()); return false; }
+#define SYM(field, name) do { *(void **)(&field) = dlsym(lib, name); if (!field) { m_err(errm, errm_len, "RCCL transport: %s missing in librccl", name); lib = nullptr; return false; } } while (0)
+        SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommInitAll, "ncclCommInitAll");
+        SYM(CommDestroy, "ncclCommDestroy"); SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd");
+        SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv"); SYM(GetErrorString, "ncclGetErrorString"); SYM(GetVersion, "ncclGetVersion");
+#undef SYM
+        return true;
+    }
+};
+Rccl g_rccl;
+constexpr int kNcclChar = 0;       // ncclInt8 / ncclChar (rccl.h): the rows travel as bytes
+
+#define M_NCCL(expr)                                                                         \
+    do {                                                                                     \
+        int e_ = (expr);                                                                     \
+        if (e_ != 0) {                                                                       \
+            m_err(errm, errm_len, "%s failed: %s (%s:%d)", #expr, g_rccl.GetErrorString(e_), \
+                  __FILE__, __LINE__);                                                       \
+            return -300 - e_;                                                                \
+        }                                                                                    \
+    } while (0)
+
+// ---- geometry ---------------------------------------------------------------------------------------
 struct Band {
-    int own0, own1, win0, win1;    // global rows (1-based, inclusive): owned band and local window
-    int L;                         // columns = lm + 1
-    long long a, b;                // global packed range [a, b) of the window
-    int rows() const { return win1 - win0 + 1; }
-    long long n_loc() const { return b - a; }
-    int loc(int grow) const { return grow - win0 + 1; }          // global row -> local row
+    int index = 0;                 // position in the chain / ring of nb bands
+    int own0 = 0, own1 = 0;        // owned global rows (1-based, inclusive)
+    int gs = 0, gn = 0;            // ghost rows on the south / north side
+    int L = 0;                     // columns = lm + 1
+    int Mr = 0;                    // rows of the ring (frames periodic in y), else 0
+    int nown() const { return own1 - own0 + 1; }
+    int rows() const { return gs + nown() + gn; }
+    long long n_loc() const { return (long long)rows() * L; }
+    int grow(int j) const {        // global row of local row j (ghosts of a ring wrap)
+        int g = own0 - gs + (j - 1);
+        if (Mr) { while (g < 1) g += Mr; while (g > Mr) g -= Mr; }
+        return g;
+    }
+    std::vector<int> row_list() const { std::vector<int> r; for (int j = 1; j <= rows(); ++j) r.push_back(grow(j)); return r; }
 };
 
-// [outer][0:n1g][inner]  ->  [outer][0:n_loc][inner]: sentinel first, then the window's cells
+// shapes of the caller's arrays around the packed index: x[outer][0:n][inner]
+struct Shape { int outer_nl, outer_c, inner; size_t outer(int nl) const { return (size_t)outer_nl * nl + outer_c; } };
+//                         fcor     h_th     h_to     nudg     fnud     hdot     tide     taus
+const Shape kStatic[8] = {{0,1,1}, {0,1,1}, {0,1,1}, {0,3,1}, {3,0,1}, {1,0,1}, {0,3,2}, {0,2,1}};
+//                        hlay     u        v        h_u      h_v      rs_h     dmdx     dmdy     v_cc     v_ll     tt3d     tb3d     tu3d
+const Shape kState[13] = {{1,0,1}, {1,0,1}, {1,0,1}, {1,0,1}, {1,0,1}, {1,0,2}, {1,0,3}, {1,0,3}, {1,0,1}, {1,0,1}, {2,0,1}, {2,0,1}, {2,0,1}};
+
+// [outer][0:n1src][inner] -> [outer][0:rows*L][inner]: sentinel first, then the listed rows of the source
 template <class T>
-std::vector<T> cut(const T *x, size_t outer, size_t inner, size_t n1g, const Band &s) {
+std::vector<T> cut(const T *x, size_t outer, size_t inner, size_t n1src, const std::vector<int> &rows, int L) {
     std::vector<T> z;
     if (!x) return z;
-    const size_t n1l = (size_t)s.n_loc() + 1;
+    const size_t n1l = rows.size() * (size_t)L + 1;
     z.resize(outer * n1l * inner);
     for (size_t o = 0; o < outer; ++o) {
-        std::memcpy(&z[o * n1l * inner], &x[o * n1g * inner], inner * sizeof(T));
-        std::memcpy(&z[(o * n1l + 1) * inner], &x[(o * n1g + (size_t)s.a) * inner], (size_t)s.n_loc() * inner * sizeof(T));
+        std::memcpy(&z[o * n1l * inner], &x[o * n1src * inner], inner * sizeof(T));
+        for (size_t r = 0; r < rows.size(); ++r)
+            std::memcpy(&z[(o * n1l + 1 + r * L) * inner], &x[(o * n1src + 1 + (size_t)(rows[r] - 1) * L) * inner],
+                        (size_t)L * inner * sizeof(T));
     }
     return z;
 }
-// owned rows of a local [outer][0:n_loc][inner] array back into the global one (+ sentinel from band 0)
+// local rows [j0, j0+n) of a local [outer][0:n1l][inner] array -> rows g(j) of a [outer][0:n1dst][inner] array
 template <class T>
-void paste(T *glob, const std::vector<T> &loc, size_t outer, size_t inner, size_t n1g, const Band &s, bool sentinel) {
-    if (!glob) return;
-    const size_t n1l = (size_t)s.n_loc() + 1;
-    const size_t la = 1 + (size_t)(s.own0 - s.win0) * s.L, lb = 1 + (size_t)(s.own1 - s.win0 + 1) * s.L;
-    const size_t ga = 1 + (size_t)(s.own0 - 1) * s.L;
+void paste(T *dst, const std::vector<T> &loc, size_t outer, size_t inner, size_t n1dst, size_t n1l, int L,
+           int j0, int n, const std::vector<int> &dst_rows, bool sentinel) {
+    if (!dst || loc.empty()) return;
     for (size_t o = 0; o < outer; ++o) {
-        if (sentinel) std::memcpy(&glob[o * n1g * inner], &loc[o * n1l * inner], inner * sizeof(T));
-        std::memcpy(&glob[(o * n1g + ga) * inner], &loc[(o * n1l + la) * inner], (lb - la) * inner * sizeof(T));
+        if (sentinel) std::memcpy(&dst[o * n1dst * inner], &loc[o * n1l * inner], inner * sizeof(T));
+        for (int r = 0; r < n; ++r)
+            std::memcpy(&dst[(o * n1dst + 1 + (size_t)(dst_rows[r] - 1) * L) * inner],
+                        &loc[(o * n1l + 1 + (size_t)(j0 - 1 + r) * L) * inner], (size_t)L * inner * sizeof(T));
     }
 }
 template <class T> const T *ptr(const std::vector<T> &v) { return v.empty() ? nullptr : v.data(); }
 template <class T> T *ptr(std::vector<T> &v) { return v.empty() ? nullptr : v.data(); }
 
+struct StaticsV {                  // one band's (or the companion frame's) static arrays in window layout
+    std::vector<double> a[8];
+    const double *bodf = nullptr;
+};
+struct StateV { std::vector<double> a[13]; };
+
+const double *const *statics_ptrs(const beom_statics *s, const double *(&p)[8]) {
+    p[0] = s->fcor; p[1] = s->h_th; p[2] = s->h_to; p[3] = s->nudg; p[4] = s->fnud; p[5] = s->hdot; p[6] = s->tide; p[7] = s->taus;
+    return p;
+}
+void state_ptrs(const beom_state *s, double *(&p)[13]) {
+    p[0] = s->hlay; p[1] = s->u; p[2] = s->v; p[3] = s->h_u; p[4] = s->h_v; p[5] = s->rs_h; p[6] = s->dmdx; p[7] = s->dmdy;
+    p[8] = s->v_cc; p[9] = s->v_ll; p[10] = s->tt3d; p[11] = s->tb3d; p[12] = s->tu3d;
+}
+
 }  // namespace
 
 struct beom_multi {
     beom_params P{};               // global frame
-    int n = 0;
+    int nb = 0;                    // bands in the chain / ring, over all processes
+    int n = 0;                     // bands of THIS process
+    bool ring = false;             // frame periodic in y
+    int xper = 0;
+    int transport = BEOM_XCHG_PEER;
+    bool local_mode = false;       // created from this band's window (beom_multi_create_local)
+    bool failed = false;           // a step failed half way: the state is undefined, only destroy is allowed
     size_t n1g = 0;
     std::vector<int> dev;
     std::vector<Band> band;
@@ -93,8 +192,23 @@ struct beom_multi {
     std::vector<hipEvent_t> packed, landed;
     std::vector<char> pending;     // an exchange into this band is in flight
     std::vector<double *> send_s, recv_s, send_n, recv_n;   // device buffers on the band's device
+    std::vector<nccl_comm> comm;
     size_t xbytes = 0;
     long long n_split = 0, n_plain = 0;   // band-steps taken in two phases / in one piece
+    // companion frame of a y-periodic ring (lives with band 0): rows 1..kMiniLo, Mr-3..Mr, Mr+1
+    beom_handle mini = nullptr;
+    int mini_k = -1;               // local index of band 0, or -1 if band 0 is not here
+    hipStream_t mini_s = nullptr;
+    double *mini_lo = nullptr, *mini_hi = nullptr;
+    hipEvent_t ev_lo = nullptr, ev_hi = nullptr, ev_free = nullptr;
+    bool lo_packed = false, free_recorded = false;
+    std::vector<int> mini_rows;
+
+    int local_of(int gidx) const { for (int k = 0; k < n; ++k) if (band[k].index == gidx) return k; return -1; }
+    bool has_s(int k) const { return ring || band[k].index > 0; }
+    bool has_n(int k) const { return ring || band[k].index < nb - 1; }
+    int south_of(int k) const { return (band[k].index - 1 + nb) % nb; }
+    int north_of(int k) const { return (band[k].index + 1) % nb; }
 };
 
 namespace {
@@ -106,8 +220,18 @@ void destroy_all(beom_multi *M) {
         if (k < (int)M->main_s.size() && M->main_s[k]) (void)hipStreamSynchronize(M->main_s[k]);
         if (k < (int)M->comm_s.size() && M->comm_s[k]) (void)hipStreamSynchronize(M->comm_s[k]);
     }
+    if (M->mini_k >= 0) {
+        (void)hipSetDevice(M->dev[M->mini_k]);
+        if (M->mini_s) (void)hipStreamSynchronize(M->mini_s);
+        if (M->mini) (void)beom_destroy(M->mini);
+        if (M->mini_lo) (void)hipFree(M->mini_lo);
+        if (M->mini_hi) (void)hipFree(M->mini_hi);
+        for (hipEvent_t e : {M->ev_lo, M->ev_hi, M->ev_free}) if (e) (void)hipEventDestroy(e);
+        if (M->mini_s) (void)hipStreamDestroy(M->mini_s);
+    }
     for (int k = 0; k < M->n; ++k) {
         (void)hipSetDevice(M->dev[k]);
+        if (k < (int)M->comm.size() && M->comm[k] && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(M->comm[k]);
         if (k < (int)M->eng.size() && M->eng[k]) (void)beom_destroy(M->eng[k]);
         for (auto *v : {&M->send_s, &M->recv_s, &M->send_n, &M->recv_n})
             if (k < (int)v->size() && (*v)[k]) (void)hipFree((*v)[k]);
@@ -119,9 +243,256 @@ void destroy_all(beom_multi *M) {
     delete M;
 }
 
+// rows of the chain / ring dealt to nb bands: equal counts, remainders to the first bands
+void deal_rows(int nrows_total, int nb, int idx, int *own0, int *own1) {
+    const int base = nrows_total / nb, rem = nrows_total % nb;
+    int j = 1;
+    for (int k = 0; k < nb; ++k) {
+        const int cnt = base + (k < rem ? 1 : 0);
+        if (k == idx) { *own0 = j; *own1 = j + cnt - 1; }
+        j += cnt;
+    }
+}
+
+int check_frame(const beom_params *prm, int nb, int yper, char *errm, int errm_len) {
+    const int L = prm->lm + 1, Mg = prm->mm + 1;
+    if (prm->abi_version != BEOM_ABI_VERSION) { m_err(errm, errm_len, "beom_multi: ABI version mismatch"); return -2; }
+    if (nb < 1 || nb > 64) { m_err(errm, errm_len, "beom_multi: bad band count %d", nb); return -3; }
+    if ((long long)prm->ndeg != (long long)L * Mg || prm->slab_mm != 0) {
+        m_err(errm, errm_len, "beom_multi: the row decomposition needs a whole dense frame (ndeg = (lm+1)(mm+1))");
+        return -3;
+    }
+    const int ring_rows = yper ? prm->mm : Mg;
+    if (ring_rows < nb * (2 * kGhost + kMiniLo)) { m_err(errm, errm_len, "beom_multi: %d rows are too few for %d bands", ring_rows, nb); return -3; }
+    if (prm->flag_nudging && prm->mcbc < 0.5) {
+        m_err(errm, errm_len, "beom_multi: mcbc = 0 (no_gradient_obc) runs on a single-device handle only");
+        return -4;
+    }
+    if (yper && prm->svis > 0.0) { m_err(errm, errm_len, "beom_multi: biharmonic viscosity on a frame periodic in y runs on a single-device handle only"); return -4; }
+    return 0;
+}
+
+// geometry of band idx; a single band of a non-periodic frame is the whole frame (no slab at all)
+Band make_band(const beom_params *prm, int nb, int idx, bool ring) {
+    Band s;
+    s.index = idx; s.L = prm->lm + 1; s.Mr = ring ? prm->mm : 0;
+    deal_rows(ring ? prm->mm : prm->mm + 1, nb, idx, &s.own0, &s.own1);
+    s.gs = (ring || idx > 0) ? kGhost : 0;
+    s.gn = (ring || idx < nb - 1) ? kGhost : 0;
+    return s;
+}
+
+// one band's engine from its window statics (tables come from the closed form)
+int create_band(beom_multi *M, int k, const StaticsV &st, char *errm, int errm_len) {
+    const Band &s = M->band[k];
+    beom_params lp = M->P;
+    lp.mm = s.rows() - 1; lp.ndeg = (int32_t)s.n_loc();
+    lp.dense_hint = 1;
+    int joff = 0, Mg = s.rows(), slab = 0;
+    if (M->ring) { joff = kFakePad; Mg = s.rows() + 2 * kFakePad; slab = 1; }                 // deep inside a taller frame
+    else if (M->nb > 1) { joff = s.own0 - s.gs - 1; Mg = M->P.mm + 1; slab = 1; }
+    lp.slab_row0 = slab ? joff : 0; lp.slab_mm = slab ? Mg - 1 : 0;
+    const beom_dense::Tables t = beom_dense::generate(s.L, s.rows(), joff, Mg, slab, M->xper, 0);
+    int rc = beom_create(&lp, M->dev[k], t.neig.data(), t.subc.data(), t.mk_u.data(), t.mk_v.data(), t.mk_n.data(),
+                         t.mkpe.data(), t.mkpi.data(), ptr(st.a[0]), ptr(st.a[1]), ptr(st.a[2]), ptr(st.a[3]), ptr(st.a[4]),
+                         ptr(st.a[5]), ptr(st.a[6]), st.bodf, ptr(st.a[7]), &M->eng[k], errm, errm_len);
+    if (rc) return rc;
+    if (!beom_is_dense(M->eng[k])) { m_err(errm, errm_len, "beom_multi: band %d did not qualify for the dense path", s.index); return -4; }
+    M_HIP(hipSetDevice(M->dev[k]));
+    M_HIP(hipStreamCreateWithFlags(&M->main_s[k], hipStreamNonBlocking));
+    M_HIP(hipStreamCreateWithFlags(&M->comm_s[k], hipStreamNonBlocking));
+    M_HIP(hipEventCreateWithFlags(&M->packed[k], hipEventDisableTiming));
+    M_HIP(hipEventCreateWithFlags(&M->landed[k], hipEventDisableTiming));
+    if (M->has_s(k)) { M_HIP(hipMalloc((void **)&M->send_s[k], M->xbytes)); M_HIP(hipMalloc((void **)&M->recv_s[k], M->xbytes)); }
+    if (M->has_n(k)) { M_HIP(hipMalloc((void **)&M->send_n[k], M->xbytes)); M_HIP(hipMalloc((void **)&M->recv_n[k], M->xbytes)); }
+    (void)beom_set_stream(M->eng[k], (void *)M->main_s[k], 0);
+    return 0;
+}
+
+// the companion frame of a ring: a y-periodic frame of kMiniLo + kGhost + 1 rows on band 0's device
+int create_mini(beom_multi *M, const StaticsV &st, char *errm, int errm_len) {
+    const int k = M->mini_k, L = M->P.lm + 1, Mm = kMiniLo + kGhost + 1;
+    beom_params lp = M->P;
+    lp.mm = Mm - 1; lp.ndeg = Mm * L; lp.dense_hint = 1; lp.slab_row0 = 0; lp.slab_mm = 0;
+    const beom_dense::Tables t = beom_dense::generate(L, Mm, 0, Mm, 0, M->xper, 1);
+    M_RC(beom_create(&lp, M->dev[k], t.neig.data(), t.subc.data(), t.mk_u.data(), t.mk_v.data(), t.mk_n.data(),
+                     t.mkpe.data(), t.mkpi.data(), ptr(st.a[0]), ptr(st.a[1]), ptr(st.a[2]), ptr(st.a[3]), ptr(st.a[4]),
+                     ptr(st.a[5]), ptr(st.a[6]), st.bodf, ptr(st.a[7]), &M->mini, errm, errm_len));
+    if (!beom_is_dense(M->mini)) { m_err(errm, errm_len, "beom_multi: the companion frame did not qualify for the dense path"); return -4; }
+    M_HIP(hipSetDevice(M->dev[k]));
+    M_HIP(hipStreamCreateWithFlags(&M->mini_s, hipStreamNonBlocking));
+    for (hipEvent_t *e : {&M->ev_lo, &M->ev_hi, &M->ev_free}) M_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    const size_t row = (size_t)kFields * M->P.nlay * L * sizeof(double);
+    M_HIP(hipMalloc((void **)&M->mini_lo, row * kMiniLo));
+    M_HIP(hipMalloc((void **)&M->mini_hi, row * kGhost));
+    (void)beom_set_stream(M->mini, (void *)M->mini_s, 0);
+    return 0;
+}
+
+int init_transport(beom_multi *M, const void *rccl_id, char *errm, int errm_len) {
+    const bool all_local = M->n == M->nb;
+    if (M->transport == BEOM_XCHG_PEER) {
+        if (!all_local) { m_err(errm, errm_len, "beom_multi: peer copies need all bands in one process; use BEOM_XCHG_RCCL"); return -3; }
+        for (int k = 0; k < M->n; ++k) {           // direct peer copies over xGMI where the devices allow it (already-enabled is fine)
+            M_HIP(hipSetDevice(M->dev[k]));
+            for (int q : {M->south_of(k), M->north_of(k)}) {
+                const int ql = M->local_of(q);
+                if (ql < 0 || M->dev[ql] == M->dev[k]) continue;
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, M->dev[k], M->dev[ql]) == hipSuccess && can) {
+                    hipError_t pe = hipDeviceEnablePeerAccess(M->dev[ql], 0);
+                    if (pe != hipSuccess) (void)hipGetLastError();
+                }
+            }
+        }
+        return 0;
+    }
+    if (M->transport != BEOM_XCHG_RCCL) { m_err(errm, errm_len, "beom_multi: unknown transport %d", M->transport); return -3; }
+    if (!(all_local || M->n == 1)) { m_err(errm, errm_len, "beom_multi: RCCL transport: all bands in one process, or one band per process"); return -3; }
+    if (!g_rccl.load(errm, errm_len)) return -31;
+    M->comm.assign(M->n, nullptr);
+    if (all_local && !rccl_id) {
+        for (int k = 0; k < M->n; ++k)
+            for (int q = 0; q < k; ++q)
+                if (M->dev[k] == M->dev[q]) { m_err(errm, errm_len, "beom_multi: RCCL needs one distinct device per band (device %d named twice)", M->dev[k]); return -3; }
+        M_NCCL(g_rccl.CommInitAll(M->comm.data(), M->n, M->dev.data()));
+    } else {
+        if (!rccl_id) { m_err(errm, errm_len, "beom_multi: RCCL transport across processes needs the unique id of beom_rccl_unique_id"); return -3; }
+        nccl_uid id;
+        std::memcpy(&id, rccl_id, sizeof(id));
+        M_HIP(hipSetDevice(M->dev[0]));
+        M_NCCL(g_rccl.CommInitRank(&M->comm[0], M->nb, id, M->band[0].index));
+    }
+    return 0;
+}
+
+void size_vectors(beom_multi *M) {
+    const int n = M->n;
+    M->eng.assign(n, nullptr);
+    M->main_s.assign(n, nullptr); M->comm_s.assign(n, nullptr);
+    M->packed.assign(n, nullptr); M->landed.assign(n, nullptr);
+    M->pending.assign(n, 0);
+    M->send_s.assign(n, nullptr); M->recv_s.assign(n, nullptr);
+    M->send_n.assign(n, nullptr); M->recv_n.assign(n, nullptr);
+    M->xbytes = (size_t)kFields * M->P.nlay * kGhost * (M->P.lm + 1) * sizeof(double);
+}
+
+std::vector<int> mini_row_list(int Mr) {
+    std::vector<int> r;
+    for (int j = 1; j <= kMiniLo; ++j) r.push_back(j);
+    for (int j = Mr - kGhost + 1; j <= Mr; ++j) r.push_back(j);
+    r.push_back(Mr + 1);
+    return r;
+}
+
+// window layout of band 0 of a ring + the orphan row -> the companion frame's layout
+// win: [outer][0:(rows*L)][inner] with local rows 1..gs = ring rows Mr-gs+1..Mr, then rows 1..; orph: [outer][0:L][inner]
+std::vector<double> mini_from_window(const double *win, const double *orph, size_t outer, size_t inner, const Band &b0) {
+    std::vector<double> z;
+    if (!win) return z;
+    const int L = b0.L, Mm = kMiniLo + kGhost + 1;
+    const size_t n1w = (size_t)b0.n_loc() + 1, n1m = (size_t)Mm * L + 1, n1o = (size_t)L + 1;
+    z.assign(outer * n1m * inner, 0.0);
+    for (size_t o = 0; o < outer; ++o) {
+        std::memcpy(&z[o * n1m * inner], &win[o * n1w * inner], inner * sizeof(double));
+        // rows 1..kMiniLo = band 0's first owned rows (local rows gs+1..)
+        std::memcpy(&z[(o * n1m + 1) * inner], &win[(o * n1w + 1 + (size_t)b0.gs * L) * inner], (size_t)kMiniLo * L * inner * sizeof(double));
+        // rows Mr-3..Mr = band 0's south ghosts (local rows 1..gs)
+        std::memcpy(&z[(o * n1m + 1 + (size_t)kMiniLo * L) * inner], &win[(o * n1w + 1) * inner], (size_t)kGhost * L * inner * sizeof(double));
+        if (orph) std::memcpy(&z[(o * n1m + 1 + (size_t)(kMiniLo + kGhost) * L) * inner], &orph[(o * n1o + 1) * inner], (size_t)L * inner * sizeof(double));
+    }
+    return z;
+}
+
 }  // namespace
 
 extern "C" {
+
+int beom_rccl_unique_id(void *id128, char *errm, int errm_len) {
+    if (!id128) { m_err(errm, errm_len, "beom_rccl_unique_id: null argument"); return -1; }
+    if (!g_rccl.load(errm, errm_len)) return -31;
+    nccl_uid id;
+    M_NCCL(g_rccl.GetUniqueId(&id));
+    std::memcpy(id128, &id, sizeof(id));
+    return 0;
+}
+
+int beom_rccl_version(char *errm, int errm_len) {
+    if (!g_rccl.load(errm, errm_len)) return -31;
+    int v = 0;
+    M_NCCL(g_rccl.GetVersion(&v));
+    return v;
+}
+
+int beom_multi_create_ex(const beom_params *prm, int ndev, const int *devices, int transport_and_flags,
+                         const int32_t *neig, const int32_t *subc,
+                         const double *mk_u, const double *mk_v, const double *mk_n,
+                         const double *mkpe, const double *mkpi,
+                         const double *fcor, const double *h_th, const double *h_to,
+                         const double *nudg, const double *fnud, const double *hdot,
+                         const double *tide, const double *bodf, const double *taus,
+                         beom_multi_handle *out, char *errm, int errm_len) {
+    if (!prm || !out || !devices || !neig || !subc || !mk_u || !mk_v || !mk_n || !mkpe || !mkpi || !fcor || !h_th || !nudg || !fnud) {
+        m_err(errm, errm_len, "beom_multi_create: null argument"); return -1;
+    }
+    *out = nullptr;
+    const int L = prm->lm + 1, Mg = prm->mm + 1, nl = prm->nlay;
+    // periodicity is encoded only in neig (private_mod.f95:614-685): W of cell (1,1) / S of cell (1,1)
+    const int xper = neig[8 * 1 + 4] != 0, yper = neig[8 * 1 + 6] != 0;
+    const int transport = transport_and_flags & 0xff;
+    const bool whole = ndev == 1 && !(yper && (transport_and_flags & BEOM_XCHG_RING1));      // one band = the frame itself
+    if (!whole) {
+        M_RC(check_frame(prm, ndev, yper, errm, errm_len));
+        if (!beom_dense::verify(L, Mg, 0, Mg, 0, xper, yper, prm->ndeg, neig, subc, mk_u, mk_v, mk_n, mkpe, mkpi)) {
+            m_err(errm, errm_len, "beom_multi_create: the row decomposition needs a dense frame (interior entirely wet)");
+            return -4;
+        }
+    } else if (prm->abi_version != BEOM_ABI_VERSION) { m_err(errm, errm_len, "beom_multi_create: ABI version mismatch"); return -2; }
+    beom_multi *M = new beom_multi();
+    M->P = *prm; M->nb = ndev; M->n = ndev; M->n1g = (size_t)prm->ndeg + 1;
+    M->ring = !whole && yper; M->xper = xper; M->transport = transport;
+    M->dev.assign(devices, devices + ndev);
+    if (getenv("BEOM_MULTI_WRAP_DEVICES")) {     // rehearsals: more bands than GPUs, ids taken modulo the visible count
+        int nvis = 0;
+        if (hipGetDeviceCount(&nvis) == hipSuccess && nvis > 0)
+            for (int &dv : M->dev) dv %= nvis;
+    }
+    size_vectors(M);
+    const size_t n1g = M->n1g;
+    int rc = 0;
+    if (whole) {                                  // the caller's own tables, any coastline
+        Band s; s.index = 0; s.own0 = 1; s.own1 = Mg; s.L = L;
+        M->band.push_back(s);
+        rc = beom_create(prm, M->dev[0], neig, subc, mk_u, mk_v, mk_n, mkpe, mkpi, fcor, h_th, h_to, nudg, fnud, hdot, tide, bodf, taus,
+                         &M->eng[0], errm, errm_len);
+        if (!rc && hipStreamCreateWithFlags(&M->main_s[0], hipStreamNonBlocking) != hipSuccess) { m_err(errm, errm_len, "hipStreamCreate failed"); rc = -100; }
+        if (!rc) (void)beom_set_stream(M->eng[0], (void *)M->main_s[0], 0);
+        if (rc) { destroy_all(M); return rc; }
+        *out = M;
+        return 0;
+    }
+    const double *src[8] = {fcor, h_th, h_to, nudg, fnud, hdot, tide, taus};
+    for (int k = 0; k < ndev && !rc; ++k) {
+        M->band.push_back(make_band(prm, ndev, k, M->ring));
+        const std::vector<int> rows = M->band[k].row_list();
+        StaticsV st;
+        for (int f = 0; f < 8; ++f) st.a[f] = cut(src[f], kStatic[f].outer(nl), kStatic[f].inner, n1g, rows, L);
+        st.bodf = bodf;
+        rc = create_band(M, k, st, errm, errm_len);
+    }
+    if (!rc && M->ring) {
+        M->mini_k = 0;
+        M->mini_rows = mini_row_list(prm->mm);
+        StaticsV st;
+        for (int f = 0; f < 8; ++f) st.a[f] = cut(src[f], kStatic[f].outer(nl), kStatic[f].inner, n1g, M->mini_rows, L);
+        st.bodf = bodf;
+        rc = create_mini(M, st, errm, errm_len);
+    }
+    if (!rc) rc = init_transport(M, nullptr, errm, errm_len);
+    if (rc) { destroy_all(M); return rc; }
+    *out = M;
+    return 0;
+}
 
 int beom_multi_create(const beom_params *prm, int ndev, const int *devices,
                       const int32_t *neig, const int32_t *subc,
@@ -131,96 +502,61 @@ int beom_multi_create(const beom_params *prm, int ndev, const int *devices,
                       const double *nudg, const double *fnud, const double *hdot,
                       const double *tide, const double *bodf, const double *taus,
                       beom_multi_handle *out, char *errm, int errm_len) {
-    if (!prm || !out || !devices || !neig || !subc) { m_err(errm, errm_len, "beom_multi_create: null argument"); return -1; }
+    const char *t = getenv("BEOM_XCHG");          // "rccl": the Fortran host picks the transport by environment
+    const int transport = (t && (!strcmp(t, "rccl") || !strcmp(t, "RCCL"))) ? BEOM_XCHG_RCCL : BEOM_XCHG_PEER;
+    return beom_multi_create_ex(prm, ndev, devices, transport, neig, subc, mk_u, mk_v, mk_n, mkpe, mkpi, fcor, h_th, h_to,
+                                nudg, fnud, hdot, tide, bodf, taus, out, errm, errm_len);
+}
+
+int beom_multi_window(const beom_params *prm, int nb, int band, int yper, int *own0, int *own1, int *ghost_s, int *ghost_n) {
+    if (!prm || nb < 1 || band < 0 || band >= nb) return -3;
+    const Band s = make_band(prm, nb, band, yper != 0);
+    if (own0) *own0 = s.own0;
+    if (own1) *own1 = s.own1;
+    if (ghost_s) *ghost_s = s.gs;
+    if (ghost_n) *ghost_n = s.gn;
+    return 0;
+}
+
+int beom_multi_create_local(const beom_params *prm, int nb, int band, int device, int xper, int yper,
+                            const void *rccl_id, const beom_statics *win, const beom_statics *orphan,
+                            beom_multi_handle *out, char *errm, int errm_len) {
+    if (!prm || !out || !win || !win->fcor || !win->h_th || !win->nudg || !win->fnud) { m_err(errm, errm_len, "beom_multi_create_local: null argument"); return -1; }
     *out = nullptr;
-    if (prm->abi_version != BEOM_ABI_VERSION) { m_err(errm, errm_len, "beom_multi_create: ABI version mismatch"); return -2; }
-    const int L = prm->lm + 1, Mg = prm->mm + 1, nl = prm->nlay;
-    if (ndev < 1 || ndev > 64) { m_err(errm, errm_len, "beom_multi_create: bad device count %d", ndev); return -3; }
-    if ((long long)prm->ndeg != (long long)L * Mg || prm->slab_mm != 0) {
-        m_err(errm, errm_len, "beom_multi_create: the row decomposition needs a whole dense frame (ndeg = (lm+1)(mm+1))");
-        return -3;
-    }
-    if (Mg < ndev * (kGhost + 1)) { m_err(errm, errm_len, "beom_multi_create: %d rows are too few for %d bands", Mg, ndev); return -3; }
-    if (prm->flag_nudging && prm->mcbc < 0.5) {
-        m_err(errm, errm_len, "beom_multi_create: mcbc = 0 (no_gradient_obc) runs on a single-device handle only");
-        return -4;
-    }
-    if (ndev > 1) {   // a frame periodic in y would need the exchange to close the ring (not offered)
-        const int32_t *nb1 = neig + 8ll * 1;               // cell (1,1): S neighbour is slot 7
-        if (nb1[6] != 0) { m_err(errm, errm_len, "beom_multi_create: frames periodic in y run on one device only"); return -4; }
+    if (band < 0 || band >= nb) { m_err(errm, errm_len, "beom_multi_create_local: band %d of %d", band, nb); return -3; }
+    M_RC(check_frame(prm, nb, yper, errm, errm_len));
+    const bool ring = yper != 0;
+    if (ring && band == 0 && (!orphan || !orphan->fcor || !orphan->h_th || !orphan->nudg || !orphan->fnud)) {
+        m_err(errm, errm_len, "beom_multi_create_local: band 0 of a frame periodic in y also carries row mm+1 (orphan statics needed)");
+        return -1;
     }
     beom_multi *M = new beom_multi();
-    M->P = *prm; M->n = ndev; M->n1g = (size_t)prm->ndeg + 1;
-    M->dev.assign(devices, devices + ndev);
-    if (getenv("BEOM_MULTI_WRAP_DEVICES")) {     // rehearsals: more bands than GPUs, ids taken modulo the visible count
-        int nvis = 0;
-        if (hipGetDeviceCount(&nvis) == hipSuccess && nvis > 0)
-            for (int &dv : M->dev) dv %= nvis;
+    M->P = *prm; M->nb = nb; M->n = 1; M->n1g = (size_t)prm->ndeg + 1;
+    M->ring = ring; M->xper = xper != 0; M->transport = BEOM_XCHG_RCCL; M->local_mode = true;
+    M->dev.assign(1, device);
+    size_vectors(M);
+    M->band.push_back(make_band(prm, nb, band, ring));
+    const Band &s = M->band[0];
+    const int nl = prm->nlay;
+    const size_t n1w = (size_t)s.n_loc() + 1;
+    const double *wp[8], *op[8];
+    statics_ptrs(win, wp);
+    StaticsV st;
+    for (int f = 0; f < 8; ++f)
+        if (wp[f]) st.a[f].assign(wp[f], wp[f] + kStatic[f].outer(nl) * n1w * kStatic[f].inner);
+    st.bodf = win->bodf;
+    int rc = create_band(M, 0, st, errm, errm_len);
+    if (!rc && ring && band == 0) {
+        M->mini_k = 0;
+        M->mini_rows = mini_row_list(prm->mm);
+        statics_ptrs(orphan, op);
+        StaticsV sm;
+        for (int f = 0; f < 8; ++f) sm.a[f] = mini_from_window(wp[f], op[f], kStatic[f].outer(nl), kStatic[f].inner, s);
+        sm.bodf = win->bodf;
+        rc = create_mini(M, sm, errm, errm_len);
     }
-    M->eng.assign(ndev, nullptr);
-    M->main_s.assign(ndev, nullptr); M->comm_s.assign(ndev, nullptr);
-    M->packed.assign(ndev, nullptr); M->landed.assign(ndev, nullptr);
-    M->pending.assign(ndev, 0);
-    M->send_s.assign(ndev, nullptr); M->recv_s.assign(ndev, nullptr);
-    M->send_n.assign(ndev, nullptr); M->recv_n.assign(ndev, nullptr);
-    M->xbytes = (size_t)kFields * nl * kGhost * L * sizeof(double);
-    // equal row counts, remainders to the first bands (dense frames: equal work)
-    const int base = Mg / ndev, rem = Mg % ndev;
-    int j = 1;
-    for (int k = 0; k < ndev; ++k) {
-        Band s{};
-        const int cnt = base + (k < rem ? 1 : 0);
-        s.own0 = j; s.own1 = j + cnt - 1; j += cnt;
-        s.win0 = k > 0 ? s.own0 - kGhost : s.own0;
-        s.win1 = k < ndev - 1 ? s.own1 + kGhost : s.own1;
-        s.L = L;
-        s.a = 1 + (long long)(s.win0 - 1) * L; s.b = 1 + (long long)s.win1 * L;
-        M->band.push_back(s);
-    }
-    const size_t n1g = M->n1g;
-    for (int k = 0; k < ndev; ++k) {
-        const Band &s = M->band[k];
-        beom_params lp = *prm;
-        lp.mm = s.rows() - 1; lp.ndeg = (int32_t)s.n_loc();
-        lp.slab_row0 = ndev > 1 ? s.win0 - 1 : 0; lp.slab_mm = ndev > 1 ? prm->mm : 0;
-        lp.dense_hint = 1;
-        std::vector<int32_t> nb = cut(neig, 1, 8, n1g, s);
-        for (int32_t &g : nb) g = (g >= s.a && g < s.b) ? (int32_t)(g - s.a + 1) : 0;   // local index, 0 outside the window
-        auto sc = cut(subc, 2, 1, n1g, s);
-        auto a_mk_u = cut(mk_u, 1, 1, n1g, s), a_mk_v = cut(mk_v, 1, 1, n1g, s), a_mk_n = cut(mk_n, 1, 1, n1g, s);
-        auto a_mkpe = cut(mkpe, 1, 1, n1g, s), a_mkpi = cut(mkpi, 1, 1, n1g, s);
-        auto a_fcor = cut(fcor, 1, 1, n1g, s), a_h_th = cut(h_th, 1, 1, n1g, s), a_h_to = cut(h_to, 1, 1, n1g, s);
-        auto a_nudg = cut(nudg, 3, 1, n1g, s), a_fnud = cut(fnud, (size_t)3 * nl, 1, n1g, s), a_hdot = cut(hdot, nl, 1, n1g, s);
-        auto a_tide = cut(tide, 3, 2, n1g, s), a_taus = cut(taus, 2, 1, n1g, s);
-        hipError_t he = hipSetDevice(M->dev[k]);
-        if (he != hipSuccess) { m_err(errm, errm_len, "hipSetDevice(%d): %s", M->dev[k], hipGetErrorString(he)); destroy_all(M); return -100 - (int)he; }
-        int rc = beom_create(&lp, M->dev[k], nb.data(), sc.data(), ptr(a_mk_u), ptr(a_mk_v), ptr(a_mk_n), ptr(a_mkpe),
-                             ptr(a_mkpi), ptr(a_fcor), ptr(a_h_th), ptr(a_h_to), ptr(a_nudg), ptr(a_fnud), ptr(a_hdot),
-                             ptr(a_tide), bodf, ptr(a_taus), &M->eng[k], errm, errm_len);
-        if (rc) { destroy_all(M); return rc; }
-        if (ndev > 1 && !beom_is_dense(M->eng[k])) {
-            m_err(errm, errm_len, "beom_multi_create: band %d did not qualify for the dense path", k);
-            destroy_all(M); return -4;
-        }
-#define M_TRY_D(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { m_err(errm, errm_len, "%s failed: %s", #expr, hipGetErrorString(e_)); destroy_all(M); return -100 - (int)e_; } } while (0)
-        M_TRY_D(hipStreamCreateWithFlags(&M->main_s[k], hipStreamNonBlocking));
-        M_TRY_D(hipStreamCreateWithFlags(&M->comm_s[k], hipStreamNonBlocking));
-        M_TRY_D(hipEventCreateWithFlags(&M->packed[k], hipEventDisableTiming));
-        M_TRY_D(hipEventCreateWithFlags(&M->landed[k], hipEventDisableTiming));
-        if (k > 0) { M_TRY_D(hipMalloc((void **)&M->send_s[k], M->xbytes)); M_TRY_D(hipMalloc((void **)&M->recv_s[k], M->xbytes)); }
-        if (k < ndev - 1) { M_TRY_D(hipMalloc((void **)&M->send_n[k], M->xbytes)); M_TRY_D(hipMalloc((void **)&M->recv_n[k], M->xbytes)); }
-        (void)beom_set_stream(M->eng[k], (void *)M->main_s[k], 0);
-        // direct peer copies over xGMI where the devices allow it (already-enabled is fine)
-        for (int nbk : {k - 1, k + 1}) {
-            if (nbk < 0 || nbk >= ndev || M->dev[nbk] == M->dev[k]) continue;
-            int can = 0;
-            if (hipDeviceCanAccessPeer(&can, M->dev[k], M->dev[nbk]) == hipSuccess && can) {
-                hipError_t pe = hipDeviceEnablePeerAccess(M->dev[nbk], 0);
-                if (pe != hipSuccess) (void)hipGetLastError();
-            }
-        }
-#undef M_TRY_D
-    }
+    if (!rc && (nb > 1 || ring)) rc = init_transport(M, rccl_id, errm, errm_len);
+    if (rc) { destroy_all(M); return rc; }
     *out = M;
     return 0;
 }
@@ -233,9 +569,15 @@ int beom_multi_band(beom_multi_handle M, int k, int *own0, int *own1, int *win0,
     if (!M || k < 0 || k >= M->n) return -3;
     if (own0) *own0 = M->band[k].own0;
     if (own1) *own1 = M->band[k].own1;
-    if (win0) *win0 = M->band[k].win0;
-    if (win1) *win1 = M->band[k].win1;
+    if (win0) *win0 = M->band[k].own0 - M->band[k].gs;        // <= 0 / > mm: ghost rows of a ring wrap
+    if (win1) *win1 = M->band[k].own1 + M->band[k].gn;
     if (device) *device = M->dev[k];
+    return 0;
+}
+
+int beom_multi_engine(beom_multi_handle M, int k, beom_handle *out) {
+    if (!M || !out || k < -1 || k >= M->n) return -3;
+    *out = k < 0 ? M->mini : M->eng[k];
     return 0;
 }
 
@@ -246,14 +588,26 @@ int beom_multi_stats(beom_multi_handle M, long long *split_band_steps, long long
     return 0;
 }
 
+int beom_multi_describe(beom_multi_handle M, int *bands_total, int *bands_local, int *transport, int *ring, int *rccl_version) {
+    if (!M) return -1;
+    if (bands_total) *bands_total = M->nb;
+    if (bands_local) *bands_local = M->n;
+    if (transport) *transport = M->transport;
+    if (ring) *ring = M->ring ? 1 : 0;
+    if (rccl_version) { *rccl_version = 0; if (g_rccl.lib) (void)g_rccl.GetVersion(rccl_version); }
+    return 0;
+}
+
 int beom_multi_sync(beom_multi_handle M, char *errm, int errm_len) {
     if (!M) { m_err(errm, errm_len, "null handle"); return -1; }
     for (int k = 0; k < M->n; ++k) {
         M_HIP(hipSetDevice(M->dev[k]));
         M_HIP(hipStreamSynchronize(M->main_s[k]));
-        M_HIP(hipStreamSynchronize(M->comm_s[k]));
+        if (M->comm_s[k]) M_HIP(hipStreamSynchronize(M->comm_s[k]));
         M->pending[k] = 0;          // whatever was in flight has landed
     }
+    if (M->mini) { M_HIP(hipSetDevice(M->dev[M->mini_k])); M_HIP(hipStreamSynchronize(M->mini_s)); }
+    M_HIP(hipGetLastError());
     return 0;
 }
 
@@ -262,18 +616,22 @@ int beom_multi_upload_state(beom_multi_handle M, const double *hlay, const doubl
                             const double *dmdy, const double *v_cc, const double *v_ll, const double *tt3d,
                             const double *tb3d, const double *tu3d, char *errm, int errm_len) {
     if (!M) { m_err(errm, errm_len, "null handle"); return -1; }
+    if (M->local_mode) { m_err(errm, errm_len, "beom_multi_upload_state: this handle holds a window (use beom_multi_upload_local)"); return -3; }
     M_RC(beom_multi_sync(M, errm, errm_len));
-    const size_t nl = (size_t)M->P.nlay, n1g = M->n1g;
-    for (int k = 0; k < M->n; ++k) {
-        const Band &s = M->band[k];
-        auto a0 = cut(hlay, nl, 1, n1g, s), a1 = cut(u, nl, 1, n1g, s), a2 = cut(v, nl, 1, n1g, s);
-        auto a3 = cut(h_u, nl, 1, n1g, s), a4 = cut(h_v, nl, 1, n1g, s);
-        auto a5 = cut(rs_h, nl, 2, n1g, s), a6 = cut(dmdx, nl, 3, n1g, s), a7 = cut(dmdy, nl, 3, n1g, s);
-        auto a8 = cut(v_cc, nl, 1, n1g, s), a9 = cut(v_ll, nl, 1, n1g, s);
-        auto b0 = cut(tt3d, 2 * nl, 1, n1g, s), b1 = cut(tb3d, 2 * nl, 1, n1g, s), b2 = cut(tu3d, 2 * nl, 1, n1g, s);
-        M_RC(beom_upload_state(M->eng[k], ptr(a0), ptr(a1), ptr(a2), ptr(a3), ptr(a4), ptr(a5), ptr(a6), ptr(a7),
-                               ptr(a8), ptr(a9), ptr(b0), ptr(b1), ptr(b2), errm, errm_len));
+    const int nl = M->P.nlay, L = M->P.lm + 1;
+    const size_t n1g = M->n1g;
+    const double *src[13] = {hlay, u, v, h_u, h_v, rs_h, dmdx, dmdy, v_cc, v_ll, tt3d, tb3d, tu3d};
+    if (M->nb == 1 && !M->ring)
+        return beom_upload_state(M->eng[0], hlay, u, v, h_u, h_v, rs_h, dmdx, dmdy, v_cc, v_ll, tt3d, tb3d, tu3d, errm, errm_len);
+    for (int k = -1; k < M->n; ++k) {
+        if (k < 0 && !M->mini) continue;
+        const std::vector<int> rows = k < 0 ? M->mini_rows : M->band[k].row_list();
+        StateV a;
+        for (int f = 0; f < 13; ++f) a.a[f] = cut(src[f], kState[f].outer(nl), kState[f].inner, n1g, rows, L);
+        M_RC(beom_upload_state(k < 0 ? M->mini : M->eng[k], ptr(a.a[0]), ptr(a.a[1]), ptr(a.a[2]), ptr(a.a[3]), ptr(a.a[4]), ptr(a.a[5]),
+                               ptr(a.a[6]), ptr(a.a[7]), ptr(a.a[8]), ptr(a.a[9]), ptr(a.a[10]), ptr(a.a[11]), ptr(a.a[12]), errm, errm_len));
     }
+    M->lo_packed = false;
     return 0;
 }
 
@@ -281,80 +639,215 @@ int beom_multi_download_state(beom_multi_handle M, double *hlay, double *u, doub
                               double *rs_h, double *dmdx, double *dmdy, double *v_cc, double *v_ll,
                               double *tt3d, double *tb3d, double *tu3d, char *errm, int errm_len) {
     if (!M) { m_err(errm, errm_len, "null handle"); return -1; }
+    if (M->local_mode) { m_err(errm, errm_len, "beom_multi_download_state: this handle holds a window (use beom_multi_download_local)"); return -3; }
     M_RC(beom_multi_sync(M, errm, errm_len));
-    const size_t nl = (size_t)M->P.nlay, n1g = M->n1g;
-    for (int k = 0; k < M->n; ++k) {
-        const Band &s = M->band[k];
-        const size_t n1l = (size_t)s.n_loc() + 1;
-        auto buf = [&](double *want, size_t per) { return std::vector<double>(want ? per * n1l : 0); };
-        auto a0 = buf(hlay, nl), a1 = buf(u, nl), a2 = buf(v, nl), a3 = buf(h_u, nl), a4 = buf(h_v, nl);
-        auto a5 = buf(rs_h, 2 * nl), a6 = buf(dmdx, 3 * nl), a7 = buf(dmdy, 3 * nl), a8 = buf(v_cc, nl), a9 = buf(v_ll, nl);
-        auto b0 = buf(tt3d, 2 * nl), b1 = buf(tb3d, 2 * nl), b2 = buf(tu3d, 2 * nl);
-        M_RC(beom_download_state(M->eng[k], ptr(a0), ptr(a1), ptr(a2), ptr(a3), ptr(a4), ptr(a5), ptr(a6), ptr(a7),
-                                 ptr(a8), ptr(a9), ptr(b0), ptr(b1), ptr(b2), errm, errm_len));
-        const bool s0 = k == 0;
-        paste(hlay, a0, nl, 1, n1g, s, s0); paste(u, a1, nl, 1, n1g, s, s0); paste(v, a2, nl, 1, n1g, s, s0);
-        paste(h_u, a3, nl, 1, n1g, s, s0); paste(h_v, a4, nl, 1, n1g, s, s0);
-        paste(rs_h, a5, nl, 2, n1g, s, s0); paste(dmdx, a6, nl, 3, n1g, s, s0); paste(dmdy, a7, nl, 3, n1g, s, s0);
-        paste(v_cc, a8, nl, 1, n1g, s, s0); paste(v_ll, a9, nl, 1, n1g, s, s0);
-        paste(tt3d, b0, 2 * nl, 1, n1g, s, s0); paste(tb3d, b1, 2 * nl, 1, n1g, s, s0); paste(tu3d, b2, 2 * nl, 1, n1g, s, s0);
+    const int nl = M->P.nlay, L = M->P.lm + 1;
+    const size_t n1g = M->n1g;
+    double *dst[13] = {hlay, u, v, h_u, h_v, rs_h, dmdx, dmdy, v_cc, v_ll, tt3d, tb3d, tu3d};
+    if (M->nb == 1 && !M->ring)
+        return beom_download_state(M->eng[0], hlay, u, v, h_u, h_v, rs_h, dmdx, dmdy, v_cc, v_ll, tt3d, tb3d, tu3d, errm, errm_len);
+    for (int k = -1; k < M->n; ++k) {
+        if (k < 0 && !M->mini) continue;
+        const size_t n1l = k < 0 ? (size_t)M->mini_rows.size() * L + 1 : (size_t)M->band[k].n_loc() + 1;
+        StateV a;
+        for (int f = 0; f < 13; ++f) if (dst[f]) a.a[f].assign(kState[f].outer(nl) * n1l * kState[f].inner, 0.0);
+        M_RC(beom_download_state(k < 0 ? M->mini : M->eng[k], ptr(a.a[0]), ptr(a.a[1]), ptr(a.a[2]), ptr(a.a[3]), ptr(a.a[4]), ptr(a.a[5]),
+                                 ptr(a.a[6]), ptr(a.a[7]), ptr(a.a[8]), ptr(a.a[9]), ptr(a.a[10]), ptr(a.a[11]), ptr(a.a[12]), errm, errm_len));
+        int j0, n;
+        std::vector<int> rows;
+        if (k < 0) { j0 = (int)M->mini_rows.size(); n = 1; rows.push_back(M->P.mm + 1); }      // the orphan row
+        else { const Band &s = M->band[k]; j0 = s.gs + 1; n = s.nown(); for (int j = 0; j < n; ++j) rows.push_back(s.own0 + j); }
+        for (int f = 0; f < 13; ++f)
+            paste(dst[f], a.a[f], kState[f].outer(nl), kState[f].inner, n1g, n1l, L, j0, n, rows, k == 0);
     }
     return 0;
 }
 
+int beom_multi_upload_local(beom_multi_handle M, const beom_state *win, const beom_state *orphan, char *errm, int errm_len) {
+    if (!M || !win) { m_err(errm, errm_len, "null argument"); return -1; }
+    if (!M->local_mode) { m_err(errm, errm_len, "beom_multi_upload_local: this handle was created from global arrays"); return -3; }
+    M_RC(beom_multi_sync(M, errm, errm_len));
+    M_RC(beom_upload_state(M->eng[0], win->hlay, win->u, win->v, win->h_u, win->h_v, win->rs_h, win->dmdx, win->dmdy,
+                           win->v_cc, win->v_ll, win->tt3d, win->tb3d, win->tu3d, errm, errm_len));
+    if (M->mini) {
+        if (!orphan) { m_err(errm, errm_len, "beom_multi_upload_local: band 0 of a ring needs the orphan row's state"); return -1; }
+        double *wp[13], *op[13];
+        state_ptrs(win, wp); state_ptrs(orphan, op);
+        StateV a;
+        for (int f = 0; f < 13; ++f) a.a[f] = mini_from_window(wp[f], op[f], kState[f].outer(M->P.nlay), kState[f].inner, M->band[0]);
+        M_RC(beom_upload_state(M->mini, ptr(a.a[0]), ptr(a.a[1]), ptr(a.a[2]), ptr(a.a[3]), ptr(a.a[4]), ptr(a.a[5]), ptr(a.a[6]),
+                               ptr(a.a[7]), ptr(a.a[8]), ptr(a.a[9]), ptr(a.a[10]), ptr(a.a[11]), ptr(a.a[12]), errm, errm_len));
+    }
+    M->lo_packed = false;
+    return 0;
+}
+
+int beom_multi_download_local(beom_multi_handle M, beom_state *win, beom_state *orphan, char *errm, int errm_len) {
+    if (!M) { m_err(errm, errm_len, "null argument"); return -1; }
+    if (!M->local_mode) { m_err(errm, errm_len, "beom_multi_download_local: this handle was created from global arrays"); return -3; }
+    M_RC(beom_multi_sync(M, errm, errm_len));
+    if (win)
+        M_RC(beom_download_state(M->eng[0], win->hlay, win->u, win->v, win->h_u, win->h_v, win->rs_h, win->dmdx, win->dmdy,
+                                 win->v_cc, win->v_ll, win->tt3d, win->tb3d, win->tu3d, errm, errm_len));
+    if (orphan && M->mini) {
+        const int nl = M->P.nlay, L = M->P.lm + 1;
+        const size_t n1m = (size_t)M->mini_rows.size() * L + 1, n1o = (size_t)L + 1;
+        double *op[13];
+        state_ptrs(orphan, op);
+        StateV a;
+        for (int f = 0; f < 13; ++f) if (op[f]) a.a[f].assign(kState[f].outer(nl) * n1m * kState[f].inner, 0.0);
+        M_RC(beom_download_state(M->mini, ptr(a.a[0]), ptr(a.a[1]), ptr(a.a[2]), ptr(a.a[3]), ptr(a.a[4]), ptr(a.a[5]), ptr(a.a[6]),
+                                 ptr(a.a[7]), ptr(a.a[8]), ptr(a.a[9]), ptr(a.a[10]), ptr(a.a[11]), ptr(a.a[12]), errm, errm_len));
+        const std::vector<int> one(1, 1);
+        for (int f = 0; f < 13; ++f)
+            paste(op[f], a.a[f], kState[f].outer(nl), kState[f].inner, n1o, n1m, L, (int)M->mini_rows.size(), 1, one, true);
+    }
+    return 0;
+}
+
+int beom_multi_profile_start(beom_multi_handle M) {
+    if (!M) return -1;
+    for (int k = 0; k < M->n; ++k) (void)beom_profile_start(M->eng[k]);
+    return 0;
+}
+// per sweep class: the slowest local band (ms summed over its launches) and that band's launch count
+int beom_multi_profile_stop(beom_multi_handle M, double *ms, int *launches, char *errm, int errm_len) {
+    if (!M || !ms || !launches) { m_err(errm, errm_len, "null argument"); return -1; }
+    M_RC(beom_multi_sync(M, errm, errm_len));
+    for (int c = 0; c < 8; ++c) { ms[c] = 0.0; launches[c] = 0; }
+    for (int k = 0; k < M->n; ++k) {
+        double m[8] = {0}; int l[8] = {0};
+        M_RC(beom_profile_stop(M->eng[k], m, l, errm, errm_len));
+        for (int c = 0; c < 7; ++c) if (m[c] > ms[c]) { ms[c] = m[c]; launches[c] = l[c]; }
+    }
+    return 0;
+}
+
+}  // extern "C"
+
+// ---- one time step of all local bands -------------------------------------------------------------
+static int multi_one_step(beom_multi *M, int t, double tres, double dtd8, double dt_r, double rsta, int n_3d,
+                          char *errm, int errm_len) {
+    const int n = M->n;
+    const int mk = M->mini_k;
+    std::vector<char> split(n, 0);
+    // the companion frame's copy of rows 1..6 (state before this step); later steps pack it right after the step
+    if (M->mini && !M->lo_packed) {
+        M_HIP(hipSetDevice(M->dev[mk]));
+        if (M->free_recorded) M_HIP(hipStreamWaitEvent(M->main_s[mk], M->ev_free, 0));
+        if (beom_pack_rows(M->eng[mk], M->band[mk].gs + 1, kMiniLo, M->mini_lo)) { m_err(errm, errm_len, "beom_pack_rows failed"); return -3; }
+        M_HIP(hipEventRecord(M->ev_lo, M->main_s[mk]));
+        M->lo_packed = true;
+    }
+    // phase 1: the rows that cannot depend on the ghosts still in flight
+    for (int k = 0; k < n; ++k) {
+        if (!M->pending[k]) continue;
+        const int rc = beom_step_phase(M->eng[k], t, tres, dtd8, dt_r, rsta, n_3d, 1, errm, errm_len);
+        if (rc == 0) split[k] = 1;
+        else if (rc != -20) return rc;
+    }
+    // ghosts of the previous step have landed (mine: before I read them; with peer copies also my
+    // neighbours': before I overwrite the send buffers they copy from)
+    for (int k = 0; k < n; ++k) {
+        M_HIP(hipSetDevice(M->dev[k]));
+        if (M->pending[k]) M_HIP(hipStreamWaitEvent(M->main_s[k], M->landed[k], 0));
+        if (M->transport == BEOM_XCHG_PEER)
+            for (int q : {M->south_of(k), M->north_of(k)}) {
+                const int ql = M->local_of(q);
+                if (ql >= 0 && ql != k && M->pending[ql]) M_HIP(hipStreamWaitEvent(M->main_s[k], M->landed[ql], 0));
+            }
+    }
+    for (int k = 0; k < n; ++k) M->pending[k] = 0;
+    // companion frame: band 0's south ghosts (rows mm-3..mm) are fresh now -> refresh, then its step
+    if (M->mini) {
+        M_HIP(hipSetDevice(M->dev[mk]));
+        if (M->free_recorded) M_HIP(hipStreamWaitEvent(M->main_s[mk], M->ev_free, 0));
+        if (beom_pack_rows(M->eng[mk], 1, kGhost, M->mini_hi)) { m_err(errm, errm_len, "beom_pack_rows failed"); return -3; }
+        M_HIP(hipEventRecord(M->ev_hi, M->main_s[mk]));
+        M_HIP(hipStreamWaitEvent(M->mini_s, M->ev_lo, 0));
+        M_HIP(hipStreamWaitEvent(M->mini_s, M->ev_hi, 0));
+        if (beom_unpack_rows(M->mini, 1, kMiniLo, M->mini_lo) || beom_unpack_rows(M->mini, kMiniLo + 1, kGhost, M->mini_hi)) {
+            m_err(errm, errm_len, "beom_unpack_rows failed"); return -3;
+        }
+        M_HIP(hipEventRecord(M->ev_free, M->mini_s));
+        M->free_recorded = true;
+        M_RC(beom_step(M->mini, t, 1, tres, dtd8, dt_r, rsta, n_3d, errm, errm_len));
+    }
+    // the rest of the step, then pack what the neighbours need = my outermost OWNED rows
+    for (int k = 0; k < n; ++k) {
+        const Band &s = M->band[k];
+        if (split[k]) { M_RC(beom_step_phase(M->eng[k], t, tres, dtd8, dt_r, rsta, n_3d, 2, errm, errm_len)); ++M->n_split; }
+        else { M_RC(beom_step(M->eng[k], t, 1, tres, dtd8, dt_r, rsta, n_3d, errm, errm_len)); ++M->n_plain; }
+        if (M->has_s(k) && beom_pack_rows(M->eng[k], s.gs + 1, kGhost, M->send_s[k])) { m_err(errm, errm_len, "beom_pack_rows failed"); return -3; }
+        if (M->has_n(k) && beom_pack_rows(M->eng[k], s.gs + s.nown() - kGhost + 1, kGhost, M->send_n[k])) { m_err(errm, errm_len, "beom_pack_rows failed"); return -3; }
+        M_HIP(hipSetDevice(M->dev[k]));
+        M_HIP(hipEventRecord(M->packed[k], M->main_s[k]));
+        if (M->mini && k == mk) {                  // rows 1..6 after this step, for the companion frame's next step
+            M_HIP(hipStreamWaitEvent(M->main_s[k], M->ev_free, 0));
+            if (beom_pack_rows(M->eng[k], s.gs + 1, kMiniLo, M->mini_lo)) { m_err(errm, errm_len, "beom_pack_rows failed"); return -3; }
+            M_HIP(hipEventRecord(M->ev_lo, M->main_s[k]));
+        }
+    }
+    // exchange on the second streams; a band's own step has read its ghosts once packed[k] is reached
+    for (int k = 0; k < n; ++k) {
+        M_HIP(hipSetDevice(M->dev[k]));
+        M_HIP(hipStreamWaitEvent(M->comm_s[k], M->packed[k], 0));
+    }
+    if (M->transport == BEOM_XCHG_RCCL) {
+        // sends in the order (south, north), receives in the order (north, south): with two bands in a ring, or
+        // one, both neighbours are the same peer and RCCL matches a pair's messages in issue order
+        M_NCCL(g_rccl.GroupStart());
+        for (int k = 0; k < n; ++k) {
+            M_HIP(hipSetDevice(M->dev[k]));
+            const int S = M->south_of(k), N = M->north_of(k);
+            if (M->has_s(k)) M_NCCL(g_rccl.Send(M->send_s[k], M->xbytes, kNcclChar, S, M->comm[k], M->comm_s[k]));
+            if (M->has_n(k)) M_NCCL(g_rccl.Send(M->send_n[k], M->xbytes, kNcclChar, N, M->comm[k], M->comm_s[k]));
+            if (M->has_n(k)) M_NCCL(g_rccl.Recv(M->recv_n[k], M->xbytes, kNcclChar, N, M->comm[k], M->comm_s[k]));
+            if (M->has_s(k)) M_NCCL(g_rccl.Recv(M->recv_s[k], M->xbytes, kNcclChar, S, M->comm[k], M->comm_s[k]));
+        }
+        M_NCCL(g_rccl.GroupEnd());
+    }
+    for (int k = 0; k < n; ++k) {
+        const Band &s = M->band[k];
+        M_HIP(hipSetDevice(M->dev[k]));
+        struct Restore { beom_multi *M; int k; ~Restore() { (void)beom_set_stream(M->eng[k], (void *)M->main_s[k], 0); } } restore{M, k};
+        (void)beom_set_stream(M->eng[k], (void *)M->comm_s[k], 0);
+        if (M->has_s(k)) {
+            if (M->transport == BEOM_XCHG_PEER) {
+                const int q = M->local_of(M->south_of(k));
+                if (q != k) M_HIP(hipStreamWaitEvent(M->comm_s[k], M->packed[q], 0));
+                M_HIP(hipMemcpyPeerAsync(M->recv_s[k], M->dev[k], M->send_n[q], M->dev[q], M->xbytes, M->comm_s[k]));
+            }
+            if (beom_unpack_rows(M->eng[k], 1, kGhost, M->recv_s[k])) { m_err(errm, errm_len, "beom_unpack_rows failed"); return -3; }
+        }
+        if (M->has_n(k)) {
+            if (M->transport == BEOM_XCHG_PEER) {
+                const int q = M->local_of(M->north_of(k));
+                if (q != k) M_HIP(hipStreamWaitEvent(M->comm_s[k], M->packed[q], 0));
+                M_HIP(hipMemcpyPeerAsync(M->recv_n[k], M->dev[k], M->send_s[q], M->dev[q], M->xbytes, M->comm_s[k]));
+            }
+            if (beom_unpack_rows(M->eng[k], s.gs + s.nown() + 1, kGhost, M->recv_n[k])) { m_err(errm, errm_len, "beom_unpack_rows failed"); return -3; }
+        }
+        M_HIP(hipEventRecord(M->landed[k], M->comm_s[k]));
+        M->pending[k] = 1;
+    }
+    return 0;
+}
+
+extern "C" {
+
 int beom_multi_step(beom_multi_handle M, int tstp_first, int nsteps, double tres, double dtd8, double dt_r,
                     double rsta, int n_3d, char *errm, int errm_len) {
     if (!M) { m_err(errm, errm_len, "null handle"); return -1; }
+    if (M->failed) { m_err(errm, errm_len, "beom_multi_step: an earlier step failed half way; destroy the handle"); return -30; }
     if (tstp_first < 1 || nsteps < 0 || n_3d < 1) { m_err(errm, errm_len, "beom_multi_step: bad arguments"); return -3; }
-    const int n = M->n;
-    if (n == 1) return beom_step(M->eng[0], tstp_first, nsteps, tres, dtd8, dt_r, rsta, n_3d, errm, errm_len);
-    std::vector<char> split(n);
+    if (M->nb == 1 && !M->ring) return beom_step(M->eng[0], tstp_first, nsteps, tres, dtd8, dt_r, rsta, n_3d, errm, errm_len);
     for (int t = tstp_first; t < tstp_first + nsteps; ++t) {
-        // phase 1: the rows that cannot depend on the ghosts still in flight
-        for (int k = 0; k < n; ++k) {
-            split[k] = 0;
-            if (!M->pending[k]) continue;
-            const int rc = beom_step_phase(M->eng[k], t, tres, dtd8, dt_r, rsta, n_3d, 1, errm, errm_len);
-            if (rc == 0) split[k] = 1;
-            else if (rc != -20) return rc;
-        }
-        // ghosts of the previous step have landed (mine: before I read them; my neighbours':
-        // before I overwrite the send buffers they copy from) -> the rest of the step, then pack
-        for (int k = 0; k < n; ++k) {
-            M_HIP(hipSetDevice(M->dev[k]));
-            for (int q : {k - 1, k, k + 1})
-                if (q >= 0 && q < n && M->pending[q]) M_HIP(hipStreamWaitEvent(M->main_s[k], M->landed[q], 0));
-        }
-        for (int k = 0; k < n; ++k) M->pending[k] = 0;
-        for (int k = 0; k < n; ++k) {
-            const Band &s = M->band[k];
-            if (split[k]) { M_RC(beom_step_phase(M->eng[k], t, tres, dtd8, dt_r, rsta, n_3d, 2, errm, errm_len)); ++M->n_split; }
-            else { M_RC(beom_step(M->eng[k], t, 1, tres, dtd8, dt_r, rsta, n_3d, errm, errm_len)); ++M->n_plain; }
-            // what I send = my outermost OWNED rows
-            if (k > 0 && beom_pack_rows(M->eng[k], s.loc(s.own0), kGhost, M->send_s[k])) { m_err(errm, errm_len, "beom_pack_rows failed"); return -3; }
-            if (k < n - 1 && beom_pack_rows(M->eng[k], s.loc(s.own1 - kGhost + 1), kGhost, M->send_n[k])) { m_err(errm, errm_len, "beom_pack_rows failed"); return -3; }
-            M_HIP(hipSetDevice(M->dev[k]));
-            M_HIP(hipEventRecord(M->packed[k], M->main_s[k]));
-        }
-        // exchange on the receivers' second streams: peer copy + unpack into the ghost rows
-        for (int k = 0; k < n; ++k) {
-            const Band &s = M->band[k];
-            M_HIP(hipSetDevice(M->dev[k]));
-            M_HIP(hipStreamWaitEvent(M->comm_s[k], M->packed[k], 0));      // my own step has read its ghosts
-            (void)beom_set_stream(M->eng[k], (void *)M->comm_s[k], 0);
-            if (k > 0) {
-                M_HIP(hipStreamWaitEvent(M->comm_s[k], M->packed[k - 1], 0));
-                M_HIP(hipMemcpyPeerAsync(M->recv_s[k], M->dev[k], M->send_n[k - 1], M->dev[k - 1], M->xbytes, M->comm_s[k]));
-                if (beom_unpack_rows(M->eng[k], s.loc(s.win0), kGhost, M->recv_s[k])) { m_err(errm, errm_len, "beom_unpack_rows failed"); return -3; }
-            }
-            if (k < n - 1) {
-                M_HIP(hipStreamWaitEvent(M->comm_s[k], M->packed[k + 1], 0));
-                M_HIP(hipMemcpyPeerAsync(M->recv_n[k], M->dev[k], M->send_s[k + 1], M->dev[k + 1], M->xbytes, M->comm_s[k]));
-                if (beom_unpack_rows(M->eng[k], s.loc(s.own1 + 1), kGhost, M->recv_n[k])) { m_err(errm, errm_len, "beom_unpack_rows failed"); return -3; }
-            }
-            (void)beom_set_stream(M->eng[k], (void *)M->main_s[k], 0);
-            M_HIP(hipEventRecord(M->landed[k], M->comm_s[k]));
-            M->pending[k] = 1;
+        const int rc = multi_one_step(M, t, tres, dtd8, dt_r, rsta, n_3d, errm, errm_len);
+        if (rc) {       // streams and events are in an unknown order: refuse further steps, keep destroy safe
+            M->failed = true;
+            for (int k = 0; k < M->n; ++k) { (void)beom_set_stream(M->eng[k], (void *)M->main_s[k], 0); M->pending[k] = 0; }
+            return rc;
         }
     }
     return 0;

@@ -213,17 +213,28 @@ int beom_profile_steps(beom_handle h, int tstp_first, int nsteps,
                        double tres, double dtd8, double dt_r, double rsta, int n_3d,
                        double *ms, int *launches, char *errm, int errm_len);
 
-/* ---- One process, several GPUs (SURVEY §8b "Threading", §8e) ---------------------------------
- * For hosts that stay single-process (the Fortran host under main.f95).  The whole dense frame
- * (ndeg = (lm+1)(mm+1), not periodic in y when ndev > 1) is cut into ndev bands of rows, band k
- * on HIP device devices[k] (the same device may be named more than once), each an ordinary slab
- * handle with 4 ghost rows per neighbour; per time step one exchange of hlay,u,v,h_u,h_v
- * (beom_pack_rows -> hipMemcpyPeerAsync over xGMI on the receiver's second stream ->
- * beom_unpack_rows) overlapped with phase 1 of the next step.  Arguments as beom_create /
- * beom_upload_state / beom_download_state / beom_step, with GLOBAL arrays; results are
- * bit-identical to the single-device handle.  (bench.py's N-GPU path is the other form of the
- * same scheme: one process per GPU, exchange over RCCL — beom_amd/slab.py.) */
+/* ---- Several GPUs: the frame cut into bands of rows (SURVEY §8b "Threading", §8e) -------------
+ * No reference counterpart (the reference is OpenMP only).  The whole DENSE frame (ndeg = (lm+1)(mm+1))
+ * is cut into bands of rows, one band per HIP device, each an ordinary slab handle with 4 ghost rows
+ * per neighbour; per time step ONE exchange of hlay,u,v,h_u,h_v (beom_pack_rows -> transport ->
+ * beom_unpack_rows on the band's second stream) overlapped with phase 1 of the next step; the steps of
+ * one beom_multi_step call run inside the library.  Results are bit-identical to the single handle.
+ * Frames periodic in y: the bands form a ring over rows 1..mm and row mm+1 (which nothing points to but
+ * every record contains, private_mod.f95:642-668) is carried by a small companion frame next to band 0.
+ *
+ * Transports of the exchange: */
+#define BEOM_XCHG_PEER 0     /* hipMemcpyPeerAsync between the bands of ONE process (xGMI peer copies)      */
+#define BEOM_XCHG_RCCL 1     /* grouped ncclSend/ncclRecv (librccl.so.1, bound at run time): all bands in one
+                                process (ncclCommInitAll, distinct devices) or one band per process          */
+#define BEOM_XCHG_RING1 0x100 /* flag for beom_multi_create_ex: cut a frame periodic in y as a ring even when
+                                there is ONE band (it then exchanges with itself; exercises the ring form)   */
+
 typedef struct beom_multi *beom_multi_handle;
+
+/* (a) From GLOBAL arrays, all bands in this process — arguments as beom_create / beom_upload_state /
+ * beom_download_state / beom_step.  Band k runs on HIP device devices[k] (with peer copies the same device may
+ * be named more than once).  This is what the Fortran host under main.f95 uses (BEOM_NGPU); beom_multi_create
+ * takes the transport from the environment (BEOM_XCHG=rccl), default peer copies. */
 int beom_multi_create(const beom_params *prm, int ndev, const int *devices,
                       const int32_t *neig, const int32_t *subc,
                       const double *mk_u, const double *mk_v, const double *mk_n,
@@ -232,9 +243,18 @@ int beom_multi_create(const beom_params *prm, int ndev, const int *devices,
                       const double *nudg, const double *fnud, const double *hdot,
                       const double *tide, const double *bodf, const double *taus,
                       beom_multi_handle *out, char *errm, int errm_len);
+int beom_multi_create_ex(const beom_params *prm, int ndev, const int *devices, int transport_and_flags,
+                         const int32_t *neig, const int32_t *subc,
+                         const double *mk_u, const double *mk_v, const double *mk_n,
+                         const double *mkpe, const double *mkpi,
+                         const double *fcor, const double *h_th, const double *h_to,
+                         const double *nudg, const double *fnud, const double *hdot,
+                         const double *tide, const double *bodf, const double *taus,
+                         beom_multi_handle *out, char *errm, int errm_len);
 int beom_multi_destroy(beom_multi_handle h);
-int beom_multi_count(beom_multi_handle h);
-/* band k: owned global rows own0..own1, local window win0..win1 (1-based, inclusive), device */
+int beom_multi_count(beom_multi_handle h);       /* bands of this process */
+/* band k: owned global rows own0..own1; local window = rows win0..win1 (1-based, inclusive; in a ring
+ * win0 <= 0 and win1 > mm denote wrapped ghost rows); device */
 int beom_multi_band(beom_multi_handle h, int k, int *own0, int *own1, int *win0, int *win1, int *device);
 int beom_multi_upload_state(beom_multi_handle h,
                             const double *hlay, const double *u, const double *v,
@@ -255,6 +275,42 @@ int beom_multi_step(beom_multi_handle h, int tstp_first, int nsteps,
 int beom_multi_sync(beom_multi_handle h, char *errm, int errm_len);
 /* how many band-steps ran in two phases (exchange overlapped) and how many in one piece */
 int beom_multi_stats(beom_multi_handle h, long long *split_band_steps, long long *plain_band_steps);
+int beom_multi_describe(beom_multi_handle h, int *bands_total, int *bands_local, int *transport, int *ring,
+                        int *rccl_version);
+/* the slab handle of local band k (k = -1: the companion frame of a ring, NULL if it is not here);
+ * owned by the multi handle — for introspection (beom_device_field, beom_set_option), not for stepping */
+int beom_multi_engine(beom_multi_handle h, int k, beom_handle *out);
+/* as beom_profile_start/stop: per sweep class the slowest local band */
+int beom_multi_profile_start(beom_multi_handle h);
+int beom_multi_profile_stop(beom_multi_handle h, double *ms, int *launches, char *errm, int errm_len);
+
+/* (b) ONE band per process from that band's WINDOW only (bench.py under torchrun: one process per GPU; nothing
+ * of global size exists on any rank).  prm describes the GLOBAL frame; xper/yper say whether it is periodic
+ * (with global arrays the library reads that off neig).  The window's rows, south to north:
+ *     ghost_s ghost rows | the owned rows own0..own1 | ghost_n ghost rows        (beom_multi_window)
+ * (in a ring the ghosts of the first and the last band wrap); every array has the storage of the
+ * corresponding beom_create / beom_upload_state argument for a frame of that many rows — index 0 = sentinel,
+ * then rows*(lm+1) cells.  No connectivity or mask tables: bands are dense frames, the library generates them.
+ * Band 0 of a frame periodic in y also passes row mm+1 ("orphan": index 0 + (lm+1) cells per array).
+ * Exchange over RCCL: rccl_id = the 128 bytes beom_rccl_unique_id returned on ONE rank, distributed by the caller
+ * (bench.py: through torch.distributed's store); may be NULL when nb = 1. */
+typedef struct beom_statics {
+    const double *fcor, *h_th, *h_to, *nudg, *fnud, *hdot, *tide, *bodf, *taus;   /* h_to, hdot, tide, bodf, taus may be NULL */
+} beom_statics;
+typedef struct beom_state {                                                        /* any pointer may be NULL */
+    double *hlay, *u, *v, *h_u, *h_v, *rs_h, *dmdx, *dmdy, *v_cc, *v_ll, *tt3d, *tb3d, *tu3d;
+} beom_state;
+int beom_rccl_unique_id(void *id128, char *errm, int errm_len);
+int beom_rccl_version(char *errm, int errm_len);        /* e.g. 22204, or a negative error code */
+int beom_multi_window(const beom_params *prm, int nb, int band, int yper,
+                      int *own0, int *own1, int *ghost_s, int *ghost_n);
+int beom_multi_create_local(const beom_params *prm, int nb, int band, int device, int xper, int yper,
+                            const void *rccl_id, const beom_statics *window, const beom_statics *orphan,
+                            beom_multi_handle *out, char *errm, int errm_len);
+int beom_multi_upload_local(beom_multi_handle h, const beom_state *window, const beom_state *orphan,
+                            char *errm, int errm_len);
+int beom_multi_download_local(beom_multi_handle h, beom_state *window, beom_state *orphan,
+                              char *errm, int errm_len);
 
 #ifdef __cplusplus
 }

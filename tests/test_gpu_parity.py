@@ -489,15 +489,28 @@ def test_device_side_output_records(name):
 
 
 @pytest.mark.parametrize("case,nband", [("closed_tall", 3), ("sill_tall", 2), ("stommel_tall", 2), ("soliton_xper", 2),
-                                        ("beach_tall_noleith", 3), ("closed_tall_dt3d", 3)])
+                                        ("beach_tall_noleith", 3), ("closed_tall_dt3d", 3),
+                                        ("jet_xyper_tall", 2), ("jet_xyper_tall", 3), ("jet_yper_wind_tall", 2),
+                                        ("jet_xyper_tall", 1), ("jet_xyper_tall_rccl", 1), ("closed_tall_rccl", 1)])
 def test_one_process_several_bands_match_single_handle(case, nband):
     """beom_multi_* (the single-process multi-GPU form the Fortran host uses): bands of rows, ghost
     exchange by peer copy on second streams, overlapped split steps — here with every band on
     the one GPU of the box.  The gathered state must equal the single handle's bit for bit,
-    through an upload/download round trip in the middle."""
+    through an upload/download round trip in the middle.
+    Frames periodic in y (private_mod.f95:642-668): the bands form a ring and the orphan row mm+1 is
+    carried by the companion frame; with ONE band the ring closes on itself — over peer copies, and
+    (*_rccl) over RCCL with a one-rank communicator, the only RCCL form a one-GPU box can run."""
     from beom_amd import inputs as I
     from beom_amd.grid import read_input_data
+    rccl = case.endswith("_rccl")
+    case = case[:-5] if rccl else case
+
+    def jet_wind():
+        p, files = I.case_unstable_jet(lm=131, mm=151, nlay=2, dt_s=1.5)
+        return p.replace(xper="0.", bdrg="2.e-4", tauw=["0.05", "0.02"]), files
     p, files = {
+        "jet_xyper_tall": lambda: I.case_unstable_jet(lm=131, mm=151, nlay=2, dt_s=1.5),
+        "jet_yper_wind_tall": jet_wind,
         "closed_tall": lambda: I.case_headline(150, 260, 3),
         "sill_tall": lambda: I.case_sill_exchange3d(lm=133, mm=199, nlay=4, dt_s=0.01, npts=5, sill_halfwidth=20.0),
         "stommel_tall": lambda: I.case_stommel(lm=140, mm=150, dl=50.0e3, dt_s=0.2),
@@ -508,23 +521,40 @@ def test_one_process_several_bands_match_single_handle(case, nband):
             I.case_headline(150, 260, 3)),
     }[case]()
     f = read_input_data(p, files=files)
+    yper = float(p.yper) > 0.5
     one = capi.Engine(f)
-    many = capi.MultiEngine(f, devices=[0] * nband)
+    many = capi.MultiEngine(f, devices=[0] * nband, ring1=True,
+                            transport=capi.XCHG_RCCL if rccl else capi.XCHG_PEER)
     assert many.count == nband
-    b0, b1 = many.band(0), many.band(1)
-    assert b0["own0"] == 1 and b1["own0"] == b0["own1"] + 1 and b1["win0"] == b1["own0"] - 4
+    d = many.describe()
+    assert d["ring"] == int(yper) and d["bands_total"] == nband
+    if rccl and (nband > 1 or yper):
+        assert d["rccl_version"] > 0 and "RCCL" in d["transport"]
+    b0 = many.band(0)
+    assert b0["own0"] == 1
+    if nband > 1:
+        b1 = many.band(1)
+        assert b1["own0"] == b0["own1"] + 1 and b1["win0"] == b1["own0"] - 4
     one.step(1, 9); many.step(1, 9)
     a, b = one.download(), many.download()
-    for k in STATE:
+    lossy = _fuses(p)            # the fused sweeps do not keep v_cc, v_ll (single handle and bands alike)
+    for k in (PROGNOSTIC if lossy else STATE):
         assert same(a[k], b[k]), (case, k, "after 9 steps")
+    if yper:                     # the orphan row mm+1, the sign of zero included
+        r0 = 1 + p.mm * (p.lm + 1)
+        for k in ("hlay", "u", "v", "h_u", "h_v"):
+            assert same_bits(a[k][:, r0:], b[k][:, r0:]), (case, k, "orphan row")
+        for k in ("rs_h", "dmdx", "dmdy"):
+            assert same_bits(a[k][:, r0:, :], b[k][:, r0:, :]), (case, k, "orphan row")
     many.upload(**b)                                   # round trip: scatter the gathered state again
     one.step(10, 14); many.step(10, 7); many.step(17, 7)
     a, b = one.download(), many.download()
     for k in PROGNOSTIC:
         assert same(a[k], b[k]), (case, k, "after 23 steps")
     st = many.stats()
-    assert st["split"] + st["plain"] == 23 * nband
-    if case in ("closed_tall", "beach_tall_noleith"):  # every step after the 3rd of a call sequence is split
+    if nband > 1 or yper:
+        assert st["split"] + st["plain"] == 23 * nband
+    if case in ("closed_tall", "beach_tall_noleith", "jet_xyper_tall"):  # every step after the 3rd of a call sequence is split
         assert st["split"] >= 15 * nband, st
     one.close(); many.close()
 
@@ -534,9 +564,11 @@ def test_multi_refuses_what_it_cannot_split():
     from beom_amd.grid import read_input_data
     p, files = I.case_unstable_jet(lm=40, mm=60, nlay=2, dt_s=1.5)       # periodic in y
     f = read_input_data(p, files=files)
-    with pytest.raises(capi.BeomError):
-        capi.MultiEngine(f, devices=[0, 0])
-    m = capi.MultiEngine(f, devices=[0])                                  # one band is fine
+    with pytest.raises(capi.BeomError):                                   # too few rows per band
+        capi.MultiEngine(f, devices=[0] * 5)
+    with pytest.raises(capi.BeomError):                                   # RCCL wants one device per band
+        capi.MultiEngine(f, devices=[0, 0], transport=capi.XCHG_RCCL)
+    m = capi.MultiEngine(f, devices=[0])                                  # one band = the frame itself
     m.step(1, 5)
     one = capi.Engine(f); one.step(1, 5)
     a, b = one.download(), m.download()
