@@ -1,23 +1,33 @@
 #!/usr/bin/env python3
 """bench.py — BEOM time-step throughput on MI355X (contract: see README / DESIGN.md §6).
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--case headline|sill4|beach8|jet]
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one model time step (update_h → update_mont_rvor_pvor_dive_kine →
 update_viscosity → update_u/update_v, private_mod.f95:2259-2290) of the headline
 workload of SURVEY.md §8(d): closed flat basin, 4096 x 4096 cells x 4 layers, FP64,
 g_fb=1, uadv=1, Leith viscosity every step.  State is resident in HBM when the timed
-region starts.  For N > 1 the SAME global grid is cut into N j-slabs (strong scaling)
-with a ghost-row exchange per step over RCCL (beom_amd/slab.py).
+region starts.
+
+N > 1: the SAME global grid is cut into N bands of rows (strong scaling), one process per GPU,
+every rank builds only its own rows from the recipe, and the K steps of the timed region run
+inside the library (beom_multi_step: ghost-row exchange over RCCL, overlapped with the interior
+rows of the next step).  Without a launcher (`python bench.py --gpus N`, no WORLD_SIZE in the
+environment) this script starts its own N ranks before anything touches a GPU; a WORLD_SIZE that
+disagrees with --gpus is an error.  torch.distributed (gloo) carries only the control plane:
+the RCCL unique id, barriers, the max over ranks.
 
 Prints ONE JSON line (rank 0).
 """
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -35,17 +45,40 @@ KERNEL_ORDER = ("update_h", "update_mont", "update_viscosity", "update_u", "upda
 NCLS = len(KERNEL_ORDER)
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec (≈6.3 TB/s achievable)
 
+CASES = {
+    # name: (recipe factory, description) — BASELINE.json configs; sizes overridable with --lm/--mm/--nlay
+    "headline": (lambda I, a: I.recipe_headline(a.lm or 4096, a.mm or 4096, a.nlay or 4),
+                 "closed flat basin (SURVEY §8d headline), g_fb=1 uadv=1 dvis=0.2"),
+    "sill4": (lambda I, a: I.recipe_sill_exchange3d(lm=a.lm or 4096, mm=a.mm or 512, nlay=a.nlay or 4, dt_s=30.0, npts=15,
+                                                     sill_halfwidth=50.0),
+              "sill_exchange3D recipe (BASELINE config 4): Gaussian sill, ocrp=1, N/S sponge, dvis=0.9"),
+    "beach8": (lambda I, a: I.recipe_carrier_beach(lm=a.lm or 8192, mm=a.mm or 8192, nlay=a.nlay or 8, dt_s=0.08),
+               "carrier_beach recipe replicated in y (BASELINE config 5): wetting/drying ocrp=1, W sponge, no Leith refresh"),
+    "jet": (lambda I, a: I.recipe_unstable_jet(lm=a.lm or 2048, mm=a.mm or 2048, nlay=a.nlay or 2, dt_s=50.0),
+            "unstable_jet recipe (BASELINE config 3): doubly periodic, dvis=0.2"),
+}
+
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--lm", type=int, default=4096)
-    ap.add_argument("--mm", type=int, default=4096)
-    ap.add_argument("--nlay", type=int, default=4)
+    ap.add_argument("--case", default="headline", choices=sorted(CASES))
+    ap.add_argument("--lm", type=int, default=0)
+    ap.add_argument("--mm", type=int, default=0)
+    ap.add_argument("--nlay", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="1024x1024x4")
+    ap.add_argument("--prewarm-s", type=float, default=1.0,
+                    help="seconds of untimed stepping before the W warm-up steps (clocks settle); the initial state is "
+                         "uploaded again afterwards")
+    ap.add_argument("--single-process", action="store_true",
+                    help="N > 1: ONE process drives all N devices (beom_multi_create from global arrays)")
+    ap.add_argument("--transport", default="rccl", choices=("rccl", "peer"), help="--single-process only")
+    ap.add_argument("--force-bands", action="store_true",
+                    help="rehearsal on one GPU: take the N > 1 path (rows from the recipe, beom_multi_create_local, RCCL) "
+                         "with a single band; with --case jet the ring then closes on itself over RCCL")
     return ap.parse_args()
 
 
@@ -62,69 +95,124 @@ def cpu_baseline(sample: str):
                 "sample": "%s (%s)" % (sample, str(exc)[:200])}
 
 
+def spawn_ranks(a) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (one per GPU) BEFORE
+    anything in this process touches a GPU, give them the torchrun environment, pass rank 0's line on."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BEOM_BENCH_SPAWNED="1",
+                   OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "4"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
+def gpu_sensors(pci: str | None) -> dict:
+    """Shader clock (MHz) and power (W) of the card with this PCI address, from sysfs — cheap enough to read
+    right at the edges of the timed region; None where the box does not expose them."""
+    out = {"sclk_mhz": None, "power_w": None}
+    try:
+        cards = [c for c in glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk")
+                 if pci and os.path.realpath(os.path.dirname(c)).lower().endswith(pci)]
+        if cards:
+            path = cards[0]
+            for line in open(path).read().splitlines():
+                if line.strip().endswith("*"):
+                    out["sclk_mhz"] = int("".join(ch for ch in line.split(":")[1] if ch.isdigit()))
+            hw = glob.glob(os.path.join(os.path.dirname(path), "hwmon", "hwmon*", "power1_average")) + \
+                glob.glob(os.path.join(os.path.dirname(path), "hwmon", "hwmon*", "power1_input"))
+            if hw:
+                out["power_w"] = round(int(open(hw[0]).read().strip()) / 1e6, 1)
+    except Exception:
+        pass
+    return out
+
+
 def main():
     a = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and a.gpus > 1 and not a.single_process:
+        sys.exit(spawn_ranks(a))
+    world = int(env_world or "1")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.single_process:
+        if world != 1:
+            raise SystemExit("bench.py: --single-process drives all devices from one process; do not use a launcher")
+    elif a.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE %d" % (a.gpus, world))
+
+    # the CPU leg first: no process of this job has touched a GPU yet when the reference binary is started
+    cpu = None
+    if rank == 0 and a.gpus == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(a.cpu_sample)
+
+    import numpy as np
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     ndev = max(torch.cuda.device_count(), 1)
-    backend = os.environ.get("BEOM_DIST_BACKEND", "nccl")     # "gloo": rehearsal of N ranks on one GPU
-    if local_rank >= ndev and backend == "nccl":
+    if local_rank >= ndev:
         raise SystemExit("bench.py: LOCAL_RANK %d but only %d GPUs visible" % (local_rank, ndev))
-    local_rank = local_rank % ndev
+    if a.single_process and a.gpus > ndev and a.transport == "rccl":
+        raise SystemExit("bench.py: --single-process --gpus %d but only %d GPUs visible" % (a.gpus, ndev))
+    torch.cuda.set_device(local_rank)
     if world > 1:
-        torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
-    n_gpus = world
-    if a.gpus != world and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (a.gpus, world), file=sys.stderr)
+        dist.init_process_group("gloo")          # control plane only; the ghost rows travel over RCCL inside the library
 
-    from beom_amd import capi, inputs
+    from beom_amd import capi, inputs, slab
     from beom_amd.grid import read_input_data
 
     t0 = time.time()
-    p, files = inputs.case_headline(a.lm, a.mm, a.nlay)
-    if world == 1:
-        f = read_input_data(p, files=files)
-        del files
+    recipe = CASES[a.case][0](inputs, a)
+    p = recipe.p
+    n_gpus = a.gpus
+    halo = None
+    banded = n_gpus > 1 or a.force_bands
+    if not banded:
+        f = read_input_data(p, files=recipe.rows(0, p.mm + 1))
         eng = capi.Engine(f, device=local_rank)
-        runner = eng
         dense = eng.is_dense
-        exchange_desc = None
+        reset = lambda: eng.upload(**{k: getattr(f, k) for k in capi.STATE_NAMES})
+    elif a.single_process:
+        f = read_input_data(p, files=recipe.rows(0, p.mm + 1))
+        eng = capi.MultiEngine(f, devices=[d % ndev for d in range(n_gpus)],
+                               transport=capi.XCHG_RCCL if a.transport == "rccl" else capi.XCHG_PEER)
+        dense = True
+        reset = lambda: eng.upload(**{k: getattr(f, k) for k in capi.STATE_NAMES})
     else:
-        from beom_amd import slab
-        runner = slab.SlabRunner.from_global_case(p, files, rank, world, device=local_rank,
-                                                  overlap=os.environ.get("BEOM_NO_OVERLAP") is None)
-        del files
-        dense = runner.engine.is_dense
-        # self-check on THIS machine: the overlapped exchange must give the owned rows of the plain
-        # (step, exchange, step, ...) form bit for bit; if not, time the plain form
-        verified = None
-        if runner.overlap:
-            def owned_copy():
-                a, b = runner.g.local_rows(runner.g.own0, runner.g.own1)
-                return [t[:, a:b].clone() for t in runner.engine.field_tensors().values()]
-            runner.overlap = False
-            runner.step(1, 9); runner.sync()
-            ref_rows = owned_copy()
-            runner.reset_state()
-            runner.overlap = True
-            runner.step(1, 9); runner.sync()
-            same = all(torch.equal(x, y) for x, y in zip(ref_rows, owned_copy()))
-            flag = torch.tensor([1 if same else 0], device="cuda" if backend == "nccl" else "cpu")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            verified = bool(flag.item())
-            runner.overlap = verified
-            runner.reset_state()
-            del ref_rows
-        exchange_desc = runner.describe()
-        exchange_desc["overlap_verified_bitwise_vs_plain_exchange"] = verified
+        uid = [capi.rccl_unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(uid, src=0)
+        f, geom, orphan = slab.build_band(recipe, world, rank)           # this rank's rows only
+        eng = capi.BandEngine(f, p, world, rank, device=local_rank, rccl_id=uid[0], orphan=orphan)
+        dense = True
+        reset = lambda: eng.upload()
+    if banded:
+        d = eng.describe()
+        L = p.lm + 1
+        seen = [{"rank": rank, "device": local_rank, "host": socket.gethostname(), "pid": os.getpid()}]
+        if world > 1:
+            gathered = [None] * world
+            dist.all_gather_object(gathered, seen[0])
+            seen = gathered
+        halo = {"backend": d["transport"] + (" (librccl %d)" % d["rccl_version"] if d["rccl_version"] else ""),
+                "control_plane": "torch.distributed gloo" if world > 1 else "none (one process)",
+                "ranks_seen": len(seen) if world > 1 else 1, "devices": [s["device"] for s in seen] if world > 1 else
+                [x % ndev for x in range(n_gpus)], "ranks": seen,
+                "bands": d["bands_total"], "ring_in_y": bool(d["ring"]), "ghost_rows": slab.GHOST, "exchanges_per_step": 1,
+                "fields": list(slab.EXCHANGED), "bytes_per_direction_per_step": len(slab.EXCHANGED) * p.nlay * slab.GHOST * L * 8,
+                "step_loop": "inside the library (beom_multi_step)", "state_build": "global arrays, cut by the library"
+                if a.single_process else "each rank builds its own rows from the recipe"}
     t_setup = time.time() - t0
 
     def barrier():
@@ -133,18 +221,60 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def all_min(flag: bool) -> bool:
+        if world == 1:
+            return flag
+        t = torch.tensor([1 if flag else 0])
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    # N > 1: on THIS machine the overlapped form (split steps around the exchange in flight) must reproduce the
+    # plain form (every step waits for its ghosts) bit for bit on every band
+    if banded:
+        names = ("hlay", "u", "v", "h_u", "h_v")
+        eng.set_option("overlap", 0)
+        eng.step(1, 9)
+        plain = eng.download(names)
+        reset()
+        eng.set_option("overlap", 1)
+        eng.step(1, 9)
+        over = eng.download(names)
+        same = all(np.array_equal(plain[k], over[k]) for k in names)
+        halo["overlap_verified_bitwise_vs_plain_exchange"] = all_min(same)
+        halo["band_steps_split_vs_plain"] = eng.stats()
+        if not halo["overlap_verified_bitwise_vs_plain_exchange"]:
+            eng.set_option("overlap", 0)
+        del plain, over
+        reset()
+
+    # pre-warm: untimed stepping so that the timed region does not start on idle clocks; then the initial state again
+    prewarm_steps = 0
+    if a.prewarm_s > 0:
+        tp = time.perf_counter()
+        eng.step(1, 10)
+        per = max((time.perf_counter() - tp) / 10, 1e-5)
+        chunk = max(10, int(0.25 / per))
+        prewarm_steps = 10
+        while time.perf_counter() - tp < a.prewarm_s:
+            eng.step(prewarm_steps + 1, chunk)
+            prewarm_steps += chunk
+        reset()
+
     # warm-up: steps 1..W (the first three are plain forward-backward, private_mod.f95:1859-1877)
     W = max(a.warmup, 3)
-    runner.step(1, W)
+    eng.step(1, W)
     barrier()
     K = a.steps
+    pci = capi.device_pci_bus_id(local_rank)
+    s0 = gpu_sensors(pci)
     t1 = time.perf_counter()
-    ms, nl = runner.profile_steps(W + 1, K)       # launches K steps with HIP events around each kernel, then syncs
+    ms, nl = eng.profile_steps(W + 1, K)       # K steps in ONE library call, HIP events around each kernel, then a sync
     barrier()
     t2 = time.perf_counter()
+    s1 = gpu_sensors(pci)
     elapsed = t2 - t1
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -154,10 +284,10 @@ def main():
     # a split step launches each sweep twice (interior + edge rows): account per STEP
     per_launch_ms = [ms[i] / K if nl[i] else 0.0 for i in range(NCLS)]
     dom = max(range(NCLS), key=lambda i: ms[i])
-    units_per_launch = units_per_step / world            # one launch covers this rank's slab, all layers
+    units_per_launch = units_per_step / n_gpus           # one launch covers one band, all layers
     ach = B_ALG_KERNEL[KERNEL_ORDER[dom]] * units_per_launch / (per_launch_ms[dom] * 1e-3) / 1e9
     roof = {"bound": "hbm", "kernel": KERNEL_ORDER[dom], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": ach / HBM_PEAK_GBS, "traffic": None,
+            "frac": ach / HBM_PEAK_GBS, "traffic": None, "traffic_source": None, "measured_GBs": None, "measured_frac": None,
             "avg_launch_ms": per_launch_ms[dom],
             "alg_bytes_per_launch": B_ALG_KERNEL[KERNEL_ORDER[dom]] * units_per_launch,
             "per_kernel": {KERNEL_ORDER[i]: {"avg_ms": per_launch_ms[i], "launches": nl[i],
@@ -165,10 +295,22 @@ def main():
                                                          / (per_launch_ms[i] * 1e-3) / 1e9) if nl[i] else None}
                            for i in range(NCLS) if nl[i]},
             "step_alg_GBs": B_ALG_STEP * value / 1e9, "step_frac": B_ALG_STEP * value / 1e9 / HBM_PEAK_GBS}
+    # HBM bytes per launch come from rocprofv3 PMC passes of this same command (tools/gpu_profile.sh): PMC counters
+    # cannot be read from inside the run, so the stored figure of the latest profiled build is replayed and labelled
     traffic_file = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(traffic_file) and world == 1 and (a.lm, a.mm, a.nlay) == (4096, 4096, 4):   # measured for that launch only
+    if os.path.exists(traffic_file) and n_gpus == 1 and a.case == "headline" and (p.lm, p.mm, p.nlay) == (4096, 4096, 4):
         try:
-            roof["traffic"] = json.load(open(traffic_file)).get(KERNEL_ORDER[dom])
+            tj = json.load(open(traffic_file))
+            roof["traffic"] = tj.get(KERNEL_ORDER[dom])
+            roof["traffic_source"] = ("profiles/traffic_latest.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of "
+                                      "`bench.py --steps 20 --warmup 5`, 2xFETCH_SIZE + WRITE_SIZE; replayed, not measured in this run")
+            if roof["traffic"]:
+                roof["measured_GBs"] = roof["traffic"] / (per_launch_ms[dom] * 1e-3) / 1e9
+                roof["measured_frac"] = roof["measured_GBs"] / HBM_PEAK_GBS
+            step_bytes = sum(tj.get(KERNEL_ORDER[i], 0.0) for i in range(NCLS) if nl[i])
+            if step_bytes:
+                roof["step_measured_bytes_per_update"] = step_bytes / units_per_step
+                roof["step_measured_frac"] = step_bytes / (elapsed / K) / 1e9 / HBM_PEAK_GBS
         except Exception:
             pass
 
@@ -177,23 +319,25 @@ def main():
         "n_gpus": n_gpus, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": "closed flat basin %dx%d cells x %d layers (SURVEY §8d headline; dense frame ndeg=%d), "
-                               "g_fb=1 uadv=1 dvis=0.2, FP64" % (a.lm, a.mm, a.nlay, p.ndeg),
-                   "global_cells": p.ndeg, "layers": p.nlay, "parallelism": "j-slab x%d" % world,
-                   "dense_fast_path": bool(dense), "setup_s": round(t_setup, 1)},
+        "config": {"workload": "%s: %dx%d cells x %d layers (dense frame ndeg=%d), FP64; %s"
+                               % (a.case, p.lm, p.mm, p.nlay, p.ndeg, CASES[a.case][1]),
+                   "case": a.case, "global_cells": p.ndeg, "layers": p.nlay, "parallelism": "j-slab x%d" % n_gpus,
+                   "dense_fast_path": bool(dense), "setup_s": round(t_setup, 1),
+                   "prewarm": {"seconds": a.prewarm_s, "steps": prewarm_steps,
+                               "note": "untimed; the initial state is uploaded again before the W warm-up steps"},
+                   "gpu_at_start": s0, "gpu_at_end": s1},
         "roofline": roof,
     }
-    if exchange_desc:
-        out["config"]["halo"] = exchange_desc
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(a.cpu_sample)
-    elif rank == 0:
-        out["cpu_baseline"] = None
+    if halo:
+        out["config"]["halo"] = halo
+    out["cpu_baseline"] = cpu
     if rank == 0:
         print(json.dumps(out))
+        sys.stdout.flush()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    eng.close()
 
 
 if __name__ == "__main__":

@@ -129,6 +129,8 @@ def load(path: Optional[str] = None) -> C.CDLL:
     H = C.c_void_p
     lib.beom_abi_version.restype = ci
     lib.beom_device_count.argtypes = [cp, ci]
+    lib.beom_device_pci_bus_id.argtypes = [ci, cp, ci]
+    lib.beom_device_pci_bus_id.restype = ci
     lib.beom_create.argtypes = [C.POINTER(BeomParams), ci, ipp, ipp] + [dpp] * 14 + [C.POINTER(H), cp, ci]
     lib.beom_destroy.argtypes = [H]
     lib.beom_upload_state.argtypes = [H] + [dpp] * 13 + [cp, ci]
@@ -168,6 +170,7 @@ def load(path: Optional[str] = None) -> C.CDLL:
     lib.beom_multi_stats.argtypes = [MH, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     lib.beom_multi_create_ex.argtypes = [C.POINTER(BeomParams), ci, C.POINTER(ci), ci, ipp, ipp] + [dpp] * 14 + [C.POINTER(MH), cp, ci]
     lib.beom_multi_describe.argtypes = [MH] + [C.POINTER(ci)] * 5
+    lib.beom_multi_set_option.argtypes = [MH, cp, ci]
     lib.beom_multi_engine.argtypes = [MH, ci, C.POINTER(H)]
     lib.beom_multi_profile_start.argtypes = [MH]
     lib.beom_multi_profile_stop.argtypes = [MH, dpp, C.POINTER(ci), cp, ci]
@@ -181,7 +184,7 @@ def load(path: Optional[str] = None) -> C.CDLL:
     for name in ("beom_multi_create", "beom_multi_destroy", "beom_multi_count", "beom_multi_band",
                  "beom_multi_upload_state", "beom_multi_download_state", "beom_multi_step", "beom_multi_sync",
                  "beom_multi_stats", "beom_multi_create_ex", "beom_multi_describe", "beom_multi_engine",
-                 "beom_multi_profile_start", "beom_multi_profile_stop", "beom_rccl_unique_id", "beom_rccl_version",
+                 "beom_multi_set_option", "beom_multi_profile_start", "beom_multi_profile_stop", "beom_rccl_unique_id", "beom_rccl_version",
                  "beom_multi_window", "beom_multi_create_local", "beom_multi_upload_local", "beom_multi_download_local"):
         getattr(lib, name).restype = ci
     for name in ("beom_device_count", "beom_create", "beom_destroy", "beom_upload_state",
@@ -198,7 +201,7 @@ def load(path: Optional[str] = None) -> C.CDLL:
     return lib
 
 
-EXPORTS = ("beom_abi_version", "beom_device_count", "beom_create", "beom_destroy",
+EXPORTS = ("beom_abi_version", "beom_device_count", "beom_device_pci_bus_id", "beom_create", "beom_destroy",
            "beom_upload_state", "beom_download_state", "beom_download_scratch", "beom_step",
            "beom_sync", "beom_update_h", "beom_update_mont_rvor_pvor_dive_kine",
            "beom_update_viscosity", "beom_update_u", "beom_update_v", "beom_rebuild_fluxes",
@@ -209,7 +212,7 @@ EXPORTS = ("beom_abi_version", "beom_device_count", "beom_create", "beom_destroy
            "beom_multi_create", "beom_multi_destroy", "beom_multi_count", "beom_multi_band",
            "beom_multi_upload_state", "beom_multi_download_state", "beom_multi_step", "beom_multi_sync",
            "beom_multi_stats", "beom_multi_create_ex", "beom_multi_describe", "beom_multi_engine",
-           "beom_multi_profile_start", "beom_multi_profile_stop", "beom_rccl_unique_id", "beom_rccl_version",
+           "beom_multi_set_option", "beom_multi_profile_start", "beom_multi_profile_stop", "beom_rccl_unique_id", "beom_rccl_version",
            "beom_multi_window", "beom_multi_create_local", "beom_multi_upload_local", "beom_multi_download_local")
 
 STATE_NAMES = ("hlay", "u", "v", "h_u", "h_v", "rs_h", "dmdx", "dmdy", "v_cc", "v_ll",
@@ -474,12 +477,18 @@ class MultiEngine:
         return self.profile_stop()
 
     def set_option(self, name: str, value: int):
-        """Forwarded to every local band (and the companion frame of a ring)."""
-        for k in range(-1, self.count):
-            h = C.c_void_p()
-            self._check(self.lib.beom_multi_engine(self.h, k, C.byref(h)))
-            if h.value:
-                self._check(self.lib.beom_set_option(h, name.encode(), int(value)))
+        """"overlap": split steps around the exchange in flight; other names go to every band."""
+        self._check(self.lib.beom_multi_set_option(self.h, name.encode(), int(value)))
+
+    def band_engine_handle(self, k: int) -> C.c_void_p:
+        h = C.c_void_p()
+        self._check(self.lib.beom_multi_engine(self.h, k, C.byref(h)))
+        return h
+
+
+def device_pci_bus_id(device: int) -> Optional[str]:
+    buf = C.create_string_buffer(64)
+    return buf.value.decode().lower() if load().beom_device_pci_bus_id(device, buf, 64) == 0 else None
 
 
 def rccl_unique_id() -> bytes:

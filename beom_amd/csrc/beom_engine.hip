@@ -104,6 +104,11 @@ int beom_device_count(char *errm, int errm_len) {
     return n;
 }
 
+int beom_device_pci_bus_id(int device, char *out, int out_len) {
+    if (!out || out_len < 16) return -1;
+    return hipDeviceGetPCIBusId(out, out_len, device) == hipSuccess ? 0 : -9;
+}
+
 int beom_create(const beom_params *prm, int device, const int32_t *neig, const int32_t *subc,
                 const double *mk_u, const double *mk_v, const double *mk_n, const double *mkpe,
                 const double *mkpi, const double *fcor, const double *h_th, const double *h_to,

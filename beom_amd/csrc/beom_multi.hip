@@ -184,6 +184,7 @@ struct beom_multi {
     int transport = BEOM_XCHG_PEER;
     bool local_mode = false;       // created from this band's window (beom_multi_create_local)
     bool failed = false;           // a step failed half way: the state is undefined, only destroy is allowed
+    bool overlap = true;           // split steps around the exchange in flight (beom_multi_set_option "overlap")
     size_t n1g = 0;
     std::vector<int> dev;
     std::vector<Band> band;
@@ -588,6 +589,18 @@ int beom_multi_stats(beom_multi_handle M, long long *split_band_steps, long long
     return 0;
 }
 
+// "overlap" (default 1): steps run in two phases around the ghost exchange still in flight; 0 = every step waits
+// for its ghosts first (same results; bench.py checks one form against the other on the machine at hand).
+// Any other name is forwarded to every local band (beom_set_option).
+int beom_multi_set_option(beom_multi_handle M, const char *name, int value) {
+    if (!M || !name) return -1;
+    if (!strcmp(name, "overlap")) { M->overlap = value != 0; return 0; }
+    int rc = 0;
+    for (int k = 0; k < M->n && !rc; ++k) rc = beom_set_option(M->eng[k], name, value);
+    if (!rc && M->mini) rc = beom_set_option(M->mini, name, value);
+    return rc;
+}
+
 int beom_multi_describe(beom_multi_handle M, int *bands_total, int *bands_local, int *transport, int *ring, int *rccl_version) {
     if (!M) return -1;
     if (bands_total) *bands_total = M->nb;
@@ -741,7 +754,7 @@ static int multi_one_step(beom_multi *M, int t, double tres, double dtd8, double
     }
     // phase 1: the rows that cannot depend on the ghosts still in flight
     for (int k = 0; k < n; ++k) {
-        if (!M->pending[k]) continue;
+        if (!M->pending[k] || !M->overlap) continue;
         const int rc = beom_step_phase(M->eng[k], t, tres, dtd8, dt_r, rsta, n_3d, 1, errm, errm_len);
         if (rc == 0) split[k] = 1;
         else if (rc != -20) return rc;

@@ -75,8 +75,9 @@ def default_depth(p: Params) -> np.ndarray:
     return h_2d
 
 
-def apply_h_bo(p: Params, h_2d: np.ndarray, h_bo_r4: np.ndarray, h_to_r4=None) -> np.ndarray:
-    """read_input_file('h_bo'), private_mod.f95:827-839."""
+def apply_h_bo(p: Params, h_2d: np.ndarray, h_bo_r4: np.ndarray, h_to_r4=None, window=None) -> np.ndarray:
+    """read_input_file('h_bo'), private_mod.f95:827-839.  window: the frame is a band of rows of a
+    taller frame — its first / last row is forced dry only where it is the taller frame's margin."""
     lm, mm = p.lm, p.mm
     h_2d[:, :] = 0.0
     if h_to_r4 is not None and p.topt > 0.5:
@@ -84,18 +85,26 @@ def apply_h_bo(p: Params, h_2d: np.ndarray, h_bo_r4: np.ndarray, h_to_r4=None) -
     else:
         h_2d[1:lm + 3, 1:mm + 3] = h_bo_r4.astype(f8)
     h_2d[h_2d < p.hdry] = 0.0
-    h_2d[1, :] = 0.0; h_2d[:, 1] = 0.0; h_2d[lm + 2, :] = 0.0; h_2d[:, mm + 2] = 0.0
+    h_2d[1, :] = 0.0; h_2d[lm + 2, :] = 0.0
+    if window is None or window["bottom_margin"]:
+        h_2d[:, 1] = 0.0
+    if window is None or window["top_margin"]:
+        h_2d[:, mm + 2] = 0.0
     return h_2d
 
 
-def index_grid_points(p: Params, h_2d: np.ndarray):
-    """private_mod.f95:567-764.  Returns dict with neig, subc, posc, masks, h_th."""
+def index_grid_points(p: Params, h_2d: np.ndarray, window=None):
+    """private_mod.f95:567-764.  Returns dict with neig, subc, posc, masks, h_th.
+    window: frame row 0 holds the (wet) row below a band of rows; it is looked at, not packed."""
     lm, mm, ndeg = p.lm, p.mm, p.ndeg
     wet = h_2d > p.hdry                              # [lm+4, mm+4], offset 1
     # frame cells i=0..lm+1, j=0..mm+1 → array index +1
     W = lambda di, dj: wet[1 + di:lm + 3 + di, 1 + dj:mm + 3 + dj]
     w00, wm0, w0m, wmm = W(0, 0), W(-1, 0), W(0, -1), W(-1, -1)
     incl = w00 | wm0 | w0m | wmm                     # :594-597
+    if window is not None:
+        incl = incl.copy()
+        incl[:, 0] = False
     order = np.flatnonzero(incl.ravel(order="F"))    # j outer, i inner
     i_c = order.size
     if i_c != ndeg:                                  # :604-610
@@ -212,10 +221,10 @@ def _seq_sum(a: np.ndarray, axis: int) -> np.ndarray:
     return s
 
 
-def equilibrium_h0_noocrp(p: Params, g, h_2d) -> np.ndarray:
+def equilibrium_h0_noocrp(p: Params, g, h_2d, dmax=None) -> np.ndarray:
     """private_mod.f95:154-175."""
     nlay, ndeg = p.nlay, p.ndeg
-    dmax = f8(h_2d.max())
+    dmax = f8(h_2d.max()) if dmax is None else f8(dmax)
     h_0 = np.zeros((nlay, ndeg + 1), dtype=f8)
     wetn = g["mk_n"] > 0.5
     hb = g["h_th"]                                     # = h_2d(i,j)
@@ -239,13 +248,13 @@ def _powi(x, n):
     return r
 
 
-def equilibrium_h0_ocrp(p: Params, g, h_2d) -> np.ndarray:
+def equilibrium_h0_ocrp(p: Params, g, h_2d, dmax=None) -> np.ndarray:
     """private_mod.f95:309-476 — per-cell Newton with Gaussian elimination and SOR,
     vectorised over cells (every cell performs the reference's scalar operations in
     the reference's order; converged cells are frozen)."""
     nlay, ndeg, nsal = p.nlay, p.ndeg, p.nsal
     thre = f8(p.tole)
-    dmax = f8(h_2d.max())
+    dmax = f8(h_2d.max()) if dmax is None else f8(dmax)
     rho8 = p.rhon_v
     topl = p.topl_v
     hsal = f8(p.hsal)
@@ -348,9 +357,16 @@ def fcor_mean_r4(ior4: np.ndarray) -> np.float32:
 
 
 def read_input_data(p: Params, idir: Optional[str] = None,
-                    files: Optional[Dict[str, np.ndarray]] = None) -> Fields:
+                    files: Optional[Dict[str, np.ndarray]] = None, window: Optional[dict] = None) -> Fields:
     """private_mod.f95:105-250 (without the output calls).  Inputs come from
-    ``idir/*.bin`` or from an in-memory dict of arrays (rounded to real*4 here)."""
+    ``idir/*.bin`` or from an in-memory dict of arrays (rounded to real*4 here).
+
+    window (multi-GPU, beom_amd/slab.py): the frame described by `p` and `files` is the band of rows
+    j0..j1 of a taller DENSE frame — frame row 0 is the taller frame's row j0-1 (looked at by the wet
+    tests and the (j-1) averages, never packed), frame rows 1..mm+1 are packed.  What init derives from
+    the WHOLE frame comes in through the dict: bottom_margin/top_margin (is row 0 / row mm+1 the taller
+    frame's margin), dmax/dmin (deepest / shallowest wet depth, :132-144,154-183), fcor0 and invf
+    (:933, :223-229).  No open-boundary segment table (:1060-1240; bands refuse mcbc = 0)."""
     lm, mm, nlay, ndeg = p.lm, p.mm, p.nlay, p.ndeg
 
     def get(key, shape):
@@ -366,14 +382,18 @@ def read_input_data(p: Params, idir: Optional[str] = None,
     hb = get("h_bo", (lm + 2, mm + 2))
     has = {}
     has["h_bo"] = hb is not None
+    if window is not None and hb is None:
+        raise ValueError("a window of rows needs an h_bo array")
     if hb is not None:
         h_to = get("h_to", (lm + 2, mm + 2)) if p.topt > 0.5 else None
-        apply_h_bo(p, h_2d, hb, h_to)
-    g = index_grid_points(p, h_2d)
+        apply_h_bo(p, h_2d, hb, h_to, window)
+    g = index_grid_points(p, h_2d, window)
     subc = g["subc"]
     wet = h_2d[h_2d > p.hdry]
     dmin = f8(wet.min()) if wet.size else f8(0)
     dmax = f8(h_2d.max())
+    if window is not None:
+        dmin, dmax = f8(window["dmin"]), f8(window["dmax"])
     if p.ocrp < 0.5 and nlay > 1:                                   # :137-144
         if p.topl_v[nlay - 1] * dmax + 10.0 * p.hmin >= dmin:
             raise ValueError("Please modify topl so that bathymetry is contained within lower layer.")
@@ -381,9 +401,9 @@ def read_input_data(p: Params, idir: Optional[str] = None,
         if dmin <= 10.0 * p.hmin:
             raise ValueError("Please adjust h_bo or hmin so that min(h_bo) > 10. * hmin.")
     if p.ocrp < 0.5:
-        h_0 = equilibrium_h0_noocrp(p, g, h_2d)
+        h_0 = equilibrium_h0_noocrp(p, g, h_2d, dmax)
     else:
-        h_0 = equilibrium_h0_ocrp(p, g, h_2d)
+        h_0 = equilibrium_h0_ocrp(p, g, h_2d, dmax)
     z2 = lambda: np.zeros((nlay, ndeg + 1), dtype=f8)
     hlay = h_0 * g["mk_n"][None, :]                                 # :198-200
     u, v = z2(), z2()
@@ -404,7 +424,7 @@ def read_input_data(p: Params, idir: Optional[str] = None,
         ok_v = (nd[ii, jj, IX_V] > f4(1e-9)) & (nd[ii, jm, IX_V] > f4(1e-9)) & (jj > 0)
         nudg[IX_V, 1:] = np.where(ok_v, nd[ii, jj, IX_V].astype(f8) * 0.5 + nd[ii, jm, IX_V].astype(f8) * 0.5, 0.0)
         flag_nudging = bool(np.any(nudg > 1e-9))
-        if flag_nudging:
+        if flag_nudging and window is None:
             segm = index_boundary_points(p, nd, h_2d)               # :868-871
         fnud[IX_N, :, 1:] = hlay[:, 1:]                             # :874-881
     it = get("init", (lm + 2, mm + 2, nlay, 3))
@@ -464,6 +484,10 @@ def read_input_data(p: Params, idir: Optional[str] = None,
         fcor[1:] = np.where((ii > 0) & (jj > 0), interp.astype(f8), fc[ii, jj].astype(f8))
     invf = f8(np.add.reduce(fcor) / f8(fcor.size))                  # :223 (summation order: see DESIGN.md)
     invf = f8(1.0) / invf if abs(invf) > 1.25e-5 else f8(0.0)
+    if window is not None:
+        if fc is not None:
+            fcor[0] = f8(window["fcor0"])
+        invf = f8(window["invf"])
     bv = f8(p.bvis)
     return Fields(
         p=p, neig=g["neig"], subc=subc, posc=g["posc"],

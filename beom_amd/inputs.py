@@ -139,8 +139,33 @@ def case_soliton(lm: int = 307, mm: int = 153, dt_s: float = 60.0, dt_o: float =
     return p, {"h_bo": h_bo, "fcor": fcor, "init": init}
 
 
-def case_unstable_jet(lm: int = 201, mm: int = 267, nlay: int = 1, dt_s: float = 50.0,
-                      dt_o: float = 2.0) -> Tuple[Params, Dict[str, np.ndarray]]:
+def _ndeg_y_uniform(col: np.ndarray, mm: int) -> int:
+    """get_nbr_deg_freedom of a frame whose interior rows 1..mm all hold the depth profile `col`
+    (margin rows dry): every packed row j = 1..mm+1 then has the same number of cells."""
+    f = np.zeros((col.size, 5))
+    f[:, 1:4] = np.asarray(col, dtype=np.float64)[:, None]
+    return get_nbr_deg_freedom(f) // 4 * (mm + 1)
+
+
+class Recipe:
+    """A testcase recipe that can be evaluated on any band of frame rows (multi-GPU: every rank
+    builds its own rows only, beom_amd/slab.py).  ``p`` = the global frame's parameters;
+    ``rows(ja, jb)`` = the input arrays restricted to frame rows ja..jb (0 <= ja <= jb <= mm+1,
+    inclusive; second axis) — element for element what the whole-frame arrays hold there."""
+
+    def __init__(self, p: Params, rows_fn, keys):
+        self.p, self._rows, self.keys = p, rows_fn, tuple(keys)
+
+    def rows(self, ja: int, jb: int) -> Dict[str, np.ndarray]:
+        assert 0 <= ja <= jb <= self.p.mm + 1, (ja, jb)
+        return self._rows(ja, jb)
+
+    def whole(self) -> Tuple[Params, Dict[str, np.ndarray]]:
+        return self.p, self.rows(0, self.p.mm + 1)
+
+
+def recipe_unstable_jet(lm: int = 201, mm: int = 267, nlay: int = 1, dt_s: float = 50.0,
+                        dt_o: float = 2.0) -> Recipe:
     """testcases/unstable_jet.m:10-66 (BASELINE config 3).  Script: 1 layer, dl=15e3,
     lx=3000e3, ly=4000e3 → 201×267.  Other sizes keep lx and set dl=lx/lm.  For
     nlay=2 (BASELINE asks for the multi-layer path; the script itself is 1-layer) the
@@ -150,40 +175,59 @@ def case_unstable_jet(lm: int = 201, mm: int = 267, nlay: int = 1, dt_s: float =
     lx = 3000.0e3
     dl = 15.0e3 if (lm, mm) == (201, 267) else lx / lm
     fcor = 0.5e-4
-    xx, yy = np.meshgrid(np.arange(1, lm + 3) - 1.5, np.arange(1, mm + 3) - 1.5, indexing="ij")
-    xx = xx - xx.mean()
-    yy = yy - yy.mean()
-    h_bo = hshf + 0.1 * hshf * np.cos(4.0 * np.pi * xx / lm)
-    h_bo[h_bo < 1.0] = 0.0
-    h_bo[0, :] = 0.0; h_bo[-1, :] = 0.0; h_bo[:, 0] = 0.0; h_bo[:, -1] = 0.0
+    xv = np.arange(1, lm + 3) - 1.5
+    yv = np.arange(1, mm + 3) - 1.5
+    # the script subtracts the mean of the 2-D meshgrid arrays: keep that summation (last bits)
+    xm = np.broadcast_to(xv[:, None], (lm + 2, mm + 2)).mean()
+    ym = np.broadcast_to(yv[None, :], (lm + 2, mm + 2)).mean()
+    xx = (xv - xm)[:, None]
+    hcol = hshf + 0.1 * hshf * np.cos(4.0 * np.pi * xx / lm)
+    hcol[hcol < 1.0] = 0.0
+    hcol[0] = 0.0; hcol[-1] = 0.0
     if nlay > 1:
-        h_bo = np.where(h_bo > 0, hshf, 0.0)       # layered split needs flat bottom (ocrp=0 check :137-144)
-    cext = np.sqrt(GRAV * h_bo.max())
-    ndeg = get_nbr_deg_freedom(h_bo)
-    n = np.zeros((lm + 2, mm + 2, nlay))
-    u = np.zeros((lm + 2, mm + 2, nlay))
-    v = np.zeros((lm + 2, mm + 2, nlay))
-    n[:, :, 0] = 1.0 * np.exp(-yy ** 2 / (0.1 * mm) ** 2)
-    for iy in range(1, mm + 1):
-        u[:, iy, 0] = (n[:, iy + 1, 0] - n[:, iy - 1, 0]) / (2.0 * dl) * GRAV / abs(fcor) * (-1.0)
+        hcol = np.where(hcol > 0, hshf, 0.0)       # layered split needs flat bottom (ocrp=0 check :137-144)
+    cext = np.sqrt(GRAV * hcol.max())
     if nlay == 1:
         rhon, topl = [1030.0], [0.0]
     else:
         rhon = [1029.0 + k for k in range(nlay)]
         topl = [k / nlay for k in range(nlay)]
+
+    def n0(ja, jb):                                 # surface anomaly on frame rows ja..jb
+        yy = (yv[ja:jb + 1] - ym)[None, :]
+        return 1.0 * np.exp(-yy ** 2 / (0.1 * mm) ** 2) * np.ones((lm + 2, 1))
+
+    def rows(ja, jb):
+        nj = jb - ja + 1
+        h_bo = np.repeat(hcol, nj, axis=1)
+        for j in (0, mm + 1):
+            if ja <= j <= jb:
+                h_bo[:, j - ja] = 0.0
+        n = np.zeros((lm + 2, nj, nlay)); u = np.zeros((lm + 2, nj, nlay)); v = np.zeros((lm + 2, nj, nlay))
+        n[:, :, 0] = n0(ja, jb)
+        ka, kb = max(ja, 1), min(jb, mm)            # rows 1..mm carry the geostrophic u
+        if kb >= ka:
+            ne = n0(ka - 1, kb + 1)
+            u[:, ka - ja:kb - ja + 1, 0] = (ne[:, 2:] - ne[:, :-2]) / (2.0 * dl) * GRAV / abs(fcor) * (-1.0)
         for k in range(1, nlay):
             n[:, :, k] = n[:, :, 0] * (1.0 - topl[k])
             u[:, :, k] = u[:, :, 0]
-    init = np.stack([n, u, v], axis=3)
+        return {"h_bo": h_bo, "init": np.stack([n, u, v], axis=3)}
+
+    ndeg = _ndeg_y_uniform(hcol[:, 0], mm)
     p = make_params(lm, mm, nlay, ndeg, dl, cext, fcor, rhon, topl, dt_s, dt_o, 0.0, 0.0, 0.0,
                     0.2, 0.0, 0.1, 10.0, 10.0, 1.0, 1.0, 0.0, 0.0, 0.0, 1.0, 1.0, 1.0,
                     desc="Test-case for barotropic instability")
-    return p, {"h_bo": h_bo, "init": init}
+    return Recipe(p, rows, ("h_bo", "init"))
 
 
-def case_sill_exchange3d(lm: int = 125, mm: int = 501, nlay: int = 2, dt_s: float = 30.0,
-                         dt_o: float = 0.01, npts: int = 15, sill_halfwidth: float = 50.0
-                         ) -> Tuple[Params, Dict[str, np.ndarray]]:
+def case_unstable_jet(lm: int = 201, mm: int = 267, nlay: int = 1, dt_s: float = 50.0,
+                      dt_o: float = 2.0) -> Tuple[Params, Dict[str, np.ndarray]]:
+    return recipe_unstable_jet(lm, mm, nlay, dt_s, dt_o).whole()
+
+
+def recipe_sill_exchange3d(lm: int = 125, mm: int = 501, nlay: int = 2, dt_s: float = 30.0,
+                           dt_o: float = 0.01, npts: int = 15, sill_halfwidth: float = 50.0) -> Recipe:
     """testcases/sill_exchange3D.m:6-155 (BASELINE config 4).  Script: 2 layers,
     dl=400, 125×501, rhon=[1027.47,1027.75], topl=[0,0.1428].  For nlay>2 extra
     interfaces are inserted (rhon linear, topl = 0.1428·k), the initial anomaly goes
@@ -196,39 +240,52 @@ def case_sill_exchange3d(lm: int = 125, mm: int = 501, nlay: int = 2, dt_s: floa
     else:
         rhon = list(np.linspace(1027.47, 1027.75, nlay))
         topl = [0.1428 * k for k in range(nlay)]
-    xx, yy = np.meshgrid(np.arange(1, lm + 3) - 1.5, np.arange(1, mm + 3) - 1.5, indexing="ij")
-    xx = xx * dl; yy = yy * dl
-    xx = xx - xx.mean(); yy = yy - yy.mean()
-    h_bo = hmax - hsill * np.exp(-(yy / (sill_halfwidth * dl)) ** 2)
-    ndeg = get_nbr_deg_freedom(h_bo)
-    cext = np.sqrt(GRAV * h_bo.max())
+    yv = (np.arange(1, mm + 3) - 1.5) * dl
+    ym = np.broadcast_to(yv[None, :], (lm + 2, mm + 2)).mean()     # the script's mean of the 2-D meshgrid array
+    yv = yv - ym
+    hrow = hmax - hsill * np.exp(-(yv / (sill_halfwidth * dl)) ** 2)    # depth depends on y only
+    ndeg = get_nbr_deg_freedom(np.repeat(hrow[None, :], 3, axis=0)) // 2 * (lm + 1)   # every row is wet across: (lm+1) cells per packed row
+    cext = np.sqrt(GRAV * hrow.max())
     hsal = 5.0
     hmin = hsal / 10.0
-    n = np.zeros((lm + 2, mm + 2, nlay)); u = np.zeros_like(n); v = np.zeros_like(n)
     j0 = int(np.floor(0.6 * (mm + 2) + 0.5))          # Octave round()
-    n[:, j0:, nlay - 1] = np.minimum(-h_bo[:, j0:] + hmax - 100.0 + 4.0 * hsal, 0.0)
     dt = 0.5 * dl / cext
     widt = npts * dl
-    nort = np.zeros((lm + 2, mm + 2, 3)); sout = np.zeros_like(nort)
-    for j in range(1, mm + 3):
-        xpos = min(max(j - 1.5 + npts - mm, 0.0), npts - 0.5)
-        nort[:, j - 1, 1:3] = dt * cext / widt * xpos / (npts - xpos)
-        nort[:, j - 1, 0] = dt / (31.0 * 24.0 * 3600.0) * xpos / npts
-        xpos = min(max(npts - (j - 1.5), 0.0), npts - 0.5)
-        sout[:, j - 1, 1:3] = dt * cext / widt * xpos / (npts - xpos)
-        sout[:, j - 1, 0] = dt / (31.0 * 24.0 * 3600.0) * xpos / npts
-    nudg = np.maximum(nort, sout)
-    nudg[0, :, :] = 0.0
-    nudg[-1, :, :] = 0.0
-    init = np.stack([n, u, v], axis=3)
+
+    def rows(ja, jb):
+        nj = jb - ja + 1
+        h_bo = np.repeat(hrow[None, ja:jb + 1], lm + 2, axis=0)
+        n = np.zeros((lm + 2, nj, nlay)); u = np.zeros_like(n); v = np.zeros_like(n)
+        ka = max(ja, j0)
+        if jb >= ka:
+            n[:, ka - ja:, nlay - 1] = np.minimum(-h_bo[:, ka - ja:] + hmax - 100.0 + 4.0 * hsal, 0.0)
+        nort = np.zeros((lm + 2, nj, 3)); sout = np.zeros_like(nort)
+        for j in range(ja + 1, jb + 2):
+            xpos = min(max(j - 1.5 + npts - mm, 0.0), npts - 0.5)
+            nort[:, j - 1 - ja, 1:3] = dt * cext / widt * xpos / (npts - xpos)
+            nort[:, j - 1 - ja, 0] = dt / (31.0 * 24.0 * 3600.0) * xpos / npts
+            xpos = min(max(npts - (j - 1.5), 0.0), npts - 0.5)
+            sout[:, j - 1 - ja, 1:3] = dt * cext / widt * xpos / (npts - xpos)
+            sout[:, j - 1 - ja, 0] = dt / (31.0 * 24.0 * 3600.0) * xpos / npts
+        nudg = np.maximum(nort, sout)
+        nudg[0, :, :] = 0.0
+        nudg[-1, :, :] = 0.0
+        return {"init": np.stack([n, u, v], axis=3), "h_bo": h_bo, "nudg": nudg}
+
     p = make_params(lm, mm, nlay, ndeg, dl, cext, fcor, rhon, topl, dt_s, dt_o, 0.0, 0.0, 0.0,
                     0.9, 0.0, hmin, 5.0, 5.0, 1.0, 1.0, 1.0, 1.0, 0.0, 0.0, 0.0, 0.0,
                     desc="Test-case: 3D sill exchange")
-    return p, {"init": init, "h_bo": h_bo, "nudg": nudg}
+    return Recipe(p, rows, ("init", "h_bo", "nudg"))
 
 
-def case_carrier_beach(lm: int | None = None, mm: int = 1, nlay: int = 1, dt_s: float = 0.08,
-                       dt_o: float = 5.0e-4, npts: int = 15) -> Tuple[Params, Dict[str, np.ndarray]]:
+def case_sill_exchange3d(lm: int = 125, mm: int = 501, nlay: int = 2, dt_s: float = 30.0,
+                         dt_o: float = 0.01, npts: int = 15, sill_halfwidth: float = 50.0
+                         ) -> Tuple[Params, Dict[str, np.ndarray]]:
+    return recipe_sill_exchange3d(lm, mm, nlay, dt_s, dt_o, npts, sill_halfwidth).whole()
+
+
+def recipe_carrier_beach(lm: int | None = None, mm: int = 1, nlay: int = 1, dt_s: float = 0.08,
+                         dt_o: float = 5.0e-4, npts: int = 15) -> Recipe:
     """testcases/carrier_beach.m:11-167 + its print_params call (wetting/drying,
     ocrp=1; the recipe BASELINE config 5 extends in y).  For mm>1 the 1-D profile is
     replicated along y.  For nlay>1 the column is split evenly in density."""
@@ -245,16 +302,15 @@ def case_carrier_beach(lm: int | None = None, mm: int = 1, nlay: int = 1, dt_s: 
     hmin = hsal / 10.0
     p_ = 1.0 / 8.0 / (1.0 + epsi)
     prof = np.arange(lm + 1, -1, -1, dtype=np.float64) * dl * alph
-    h_bo = np.repeat(prof[:, None], mm + 2, axis=1)
-    h_bo[:npts, 1:-1] = h_bo[npts - 1, 1:-1]
-    h_bo[:, 0] = 0.0; h_bo[:, -1] = 0.0; h_bo[-1, :] = 0.0; h_bo[0, :] = 0.0
-    ndeg = get_nbr_deg_freedom(h_bo)
-    col = h_bo[:, 1]
+    col = prof.copy()                               # one interior row of h_bo
+    col[:npts] = col[npts - 1]
+    col[-1] = 0.0; col[0] = 0.0
+    ndeg = _ndeg_y_uniform(col, mm)
     d = np.abs(col - hhti)
     i_sl = int(np.where(d == d.min())[0][0])
     hhti = col[i_sl]
-    topl0 = hhti / h_bo.max()
-    cext = np.sqrt(GRAV * h_bo.max())
+    topl0 = hhti / col.max()
+    cext = np.sqrt(GRAV * col.max())
     xref = np.arange(1, lm + 3, dtype=np.float64) * dl
     xref = xref - xref[i_sl]
     sigm = np.arange(10.0, -1e-9, -0.1)
@@ -264,52 +320,79 @@ def case_carrier_beach(lm: int | None = None, mm: int = 1, nlay: int = 1, dt_s: 
     order = np.argsort(xs)
     n1 = np.interp(xref, xs[order], es[order], left=np.nan, right=np.nan)
     n1[np.isnan(n1)] = 0.0
-    n = np.zeros((lm + 2, mm + 2, nlay)); u = np.zeros_like(n); v = np.zeros_like(n)
-    n[:, :, 0] = n1[:, None]
     # western sponge on eta,u (carrier_beach.m:121-147)
-    nudg = np.zeros((lm + 2, mm + 2, 3))
+    ncol = np.zeros((lm + 2, 3))
     dt = 0.5 * dl / cext
     widt = npts * dl
     for i in range(1, lm + 3):
         xpos = min(max(npts - (i - 1.5), 0.0), npts - 0.5)
-        nudg[i - 1, :, 0:2] = dt * cext / widt * xpos / (npts - xpos)
+        ncol[i - 1, 0:2] = dt * cext / widt * xpos / (npts - xpos)
     if nlay == 1:
         rhon, topl = [1030.0], [topl0]
     else:
         rhon = [1030.0 + 0.5 * k for k in range(nlay)]
         topl = [topl0 + (1.0 - topl0) * k / nlay for k in range(nlay)]
-    init = np.stack([n, u, v], axis=3)
+
+    def rows(ja, jb):
+        nj = jb - ja + 1
+        h_bo = np.repeat(col[:, None], nj, axis=1)
+        for j in (0, mm + 1):
+            if ja <= j <= jb:
+                h_bo[:, j - ja] = 0.0
+        n = np.zeros((lm + 2, nj, nlay)); u = np.zeros_like(n); v = np.zeros_like(n)
+        n[:, :, 0] = n1[:, None]
+        nudg = np.repeat(ncol[:, None, :], nj, axis=1)
+        return {"h_bo": h_bo, "init": np.stack([n, u, v], axis=3), "nudg": nudg}
+
     p = make_params(lm, mm, nlay, ndeg, dl, cext, 0.0, rhon, topl, dt_s, dt_o, 0.0, 0.0, 0.0,
                     0.0, 0.0, hmin, 10.0, 10.0, 1.0, 1.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0,
                     desc="Test-case for wave on sloping beach")
-    return p, {"h_bo": h_bo, "init": init, "nudg": nudg}
+    return Recipe(p, rows, ("h_bo", "init", "nudg"))
 
 
-def case_headline(lm: int = 4096, mm: int = 4096, nlay: int = 4, dvis: float = 0.2,
-                  nsteps_days: float | None = None) -> Tuple[Params, Dict[str, np.ndarray]]:
+def case_carrier_beach(lm: int | None = None, mm: int = 1, nlay: int = 1, dt_s: float = 0.08,
+                       dt_o: float = 5.0e-4, npts: int = 15) -> Tuple[Params, Dict[str, np.ndarray]]:
+    return recipe_carrier_beach(lm, mm, nlay, dt_s, dt_o, npts).whole()
+
+
+def recipe_headline(lm: int = 4096, mm: int = 4096, nlay: int = 4, dvis: float = 0.2,
+                    nsteps_days: float | None = None) -> Recipe:
     """SURVEY.md §8(d) headline: closed flat 4000 m basin, dl=1000, f0=1e-4,
     rhon=1026+0.5k, topl=k/nlay, 1 m Gaussian surface mound of radius lm/12
     (as conservation.m:75), g_fb=1, uadv=1, dvis=0.2, no forcing."""
     dl, hfla, f0 = 1000.0, 4000.0, 1.0e-4
-    h_bo = np.zeros((lm + 2, mm + 2), dtype=np.float32)
-    h_bo[1:-1, 1:-1] = hfla
     ndeg = (lm + 1) * (mm + 1)
     cext = np.sqrt(GRAV * hfla)
     rhon = [1026.0 + 0.5 * k for k in range(nlay)]
     topl = [k / nlay for k in range(nlay)]
     x = (np.arange(lm + 2, dtype=np.float64) - 0.5 * (lm + 1))[:, None]
-    y = (np.arange(mm + 2, dtype=np.float64) - 0.5 * (mm + 1))[None, :]
+    yall = np.arange(mm + 2, dtype=np.float64) - 0.5 * (mm + 1)
     rad = lm / 12.0
-    mound = np.exp(-(x * x + y * y) / rad ** 2).astype(np.float32)
-    init = np.zeros((lm + 2, mm + 2, nlay, 3), dtype=np.float32)
-    for k in range(nlay):
-        init[:, :, k, 0] = mound * np.float32(1.0 - topl[k])
+
+    def rows(ja, jb):
+        nj = jb - ja + 1
+        h_bo = np.zeros((lm + 2, nj), dtype=np.float32)
+        ka, kb = max(ja, 1), min(jb, mm)
+        if kb >= ka:
+            h_bo[1:-1, ka - ja:kb - ja + 1] = hfla
+        y = yall[None, ja:jb + 1]
+        mound = np.exp(-(x * x + y * y) / rad ** 2).astype(np.float32)
+        init = np.zeros((lm + 2, nj, nlay, 3), dtype=np.float32)
+        for k in range(nlay):
+            init[:, :, k, 0] = mound * np.float32(1.0 - topl[k])
+        return {"h_bo": h_bo, "init": init}
+
     dt = 0.5 * dl / cext
     dt_s = nsteps_days if nsteps_days is not None else 110.0 * dt / 86400.0
     p = make_params(lm, mm, nlay, ndeg, dl, cext, f0, rhon, topl, dt_s, 1.0e3, 0.0, 0.0, 0.0,
                     dvis, 0.0, 1.0, 10.0, 10.0, 1.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0,
                     desc="Headline closed basin")
-    return p, {"h_bo": h_bo, "init": init}
+    return Recipe(p, rows, ("h_bo", "init"))
+
+
+def case_headline(lm: int = 4096, mm: int = 4096, nlay: int = 4, dvis: float = 0.2,
+                  nsteps_days: float | None = None) -> Tuple[Params, Dict[str, np.ndarray]]:
+    return recipe_headline(lm, mm, nlay, dvis, nsteps_days).whole()
 
 
 # ---- further recipes of testcases/*.m (input halves), sizes reducible for fixtures -----------------

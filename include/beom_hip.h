@@ -78,6 +78,8 @@ int beom_abi_version(void);
 const char *beom_source_hash(void);
 /* Number of visible HIP devices, or a negative error code. */
 int beom_device_count(char *errm, int errm_len);
+/* PCI address "dddd:bb:dd.f" of a HIP device (to find its sysfs node for clock / power read-outs). */
+int beom_device_pci_bus_id(int device, char *out, int out_len);
 
 /* Replaces the static part of the module state built by read_input_data
  * (private_mod.f95:105-250): connectivity (index_grid_points :567-764), masks,
@@ -275,6 +277,8 @@ int beom_multi_step(beom_multi_handle h, int tstp_first, int nsteps,
 int beom_multi_sync(beom_multi_handle h, char *errm, int errm_len);
 /* how many band-steps ran in two phases (exchange overlapped) and how many in one piece */
 int beom_multi_stats(beom_multi_handle h, long long *split_band_steps, long long *plain_band_steps);
+/* "overlap" (default 1; 0 = every step waits for its ghost rows before it starts); other names go to every band */
+int beom_multi_set_option(beom_multi_handle h, const char *name, int value);
 int beom_multi_describe(beom_multi_handle h, int *bands_total, int *bands_local, int *transport, int *ring,
                         int *rccl_version);
 /* the slab handle of local band k (k = -1: the companion frame of a ring, NULL if it is not here);

@@ -62,3 +62,44 @@ def _free_port():
 def test_two_ranks_on_one_gpu_match_single_domain(overlap):
     import torch.multiprocessing as mp
     mp.spawn(_worker, args=(2, _free_port(), overlap, 14), nprocs=2, join=True)
+
+
+@pytest.mark.parametrize("case", ["jet_ring_of_one", "closed_single_band"])
+def test_band_from_recipe_rows_matches_single_handle(case):
+    """beom_multi_create_local — what every rank of bench.py's N-GPU run does: the band's rows come from the
+    recipe alone, the library generates connectivity and masks, the exchange runs over RCCL.  A one-GPU box
+    can hold one rank: for the y-periodic jet its ring closes on itself (self send/recv over a one-rank RCCL
+    communicator, companion frame for the orphan row); results must equal the single handle's bit for bit."""
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import numpy as np
+    from beom_amd import capi, inputs as I, slab
+    from beom_amd.grid import read_input_data
+    from helpers import same, same_bits
+    recipe = I.recipe_unstable_jet(lm=131, mm=151, nlay=2, dt_s=1.5) if case == "jet_ring_of_one" else I.recipe_headline(150, 131, 3)
+    p = recipe.p
+    yper = float(p.yper) > 0.5
+    f, g, orphan = slab.build_band(recipe, 1, 0)
+    assert (orphan is not None) == yper and g.rows == (p.mm + 2 * slab.GHOST if yper else p.mm + 1)
+    band = capi.BandEngine(f, p, 1, 0, device=0, rccl_id=capi.rccl_unique_id() if yper else None, orphan=orphan)
+    assert band.describe()["ring"] == int(yper)
+    whole = capi.Engine(read_input_data(p, files=recipe.rows(0, p.mm + 1)))
+    band.step(1, 7); band.step(8, 6)
+    whole.step(1, 13)
+    ref = whole.download()
+    st, so = band.download(orphan=True)
+    L = p.lm + 1
+    a, b = 1 + (g.own0 - 1) * L, 1 + g.own1 * L
+    la, lb = g.local_rows(g.own0, g.own1)
+    for k in ("hlay", "u", "v", "h_u", "h_v"):
+        assert same(st[k][:, la:lb], ref[k][:, a:b]), k
+        if yper:
+            assert same_bits(so[k][:, 1:], ref[k][:, -L:]), ("orphan row", k)
+    for k in ("rs_h", "dmdx", "dmdy"):
+        assert same(st[k][:, la:lb, :], ref[k][:, a:b, :]), k
+        if yper:
+            assert same_bits(so[k][:, 1:, :], ref[k][:, -L:, :]), ("orphan row", k)
+    if yper:
+        assert band.stats()["split"] >= 9
+    band.close(); whole.close()
