@@ -264,7 +264,8 @@ int check_frame(const beom_params *prm, int nb, int yper, char *errm, int errm_l
         return -3;
     }
     const int ring_rows = yper ? prm->mm : Mg;
-    if (ring_rows < nb * (2 * kGhost + kMiniLo)) { m_err(errm, errm_len, "beom_multi: %d rows are too few for %d bands", ring_rows, nb); return -3; }
+    // every band sends its outermost kGhost owned rows; band 0 of a ring also lends rows 1..kMiniLo to the companion frame
+    if (ring_rows < nb * (yper ? (kGhost > kMiniLo ? kGhost : kMiniLo) : kGhost + 1)) { m_err(errm, errm_len, "beom_multi: %d rows are too few for %d bands", ring_rows, nb); return -3; }
     if (prm->flag_nudging && prm->mcbc < 0.5) {
         m_err(errm, errm_len, "beom_multi: mcbc = 0 (no_gradient_obc) runs on a single-device handle only");
         return -4;

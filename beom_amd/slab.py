@@ -100,7 +100,7 @@ def decompose(mm: int, lm: int, world: int, ghost: int = GHOST, yper: bool = Fal
     nothing points to, is carried by the companion frame — mini_rows)."""
     Mg, L = mm + 1, lm + 1
     nrows = mm if yper else Mg
-    if world < 1 or nrows < world * (2 * ghost + MINI_LO):
+    if world < 1 or nrows < world * (max(ghost, MINI_LO) if yper else ghost + 1):
         raise ValueError("too few rows (%d) for %d slabs with %d ghost rows" % (nrows, world, ghost))
     base, rem = divmod(nrows, world)
     out, j = [], 1

@@ -565,7 +565,7 @@ def test_multi_refuses_what_it_cannot_split():
     p, files = I.case_unstable_jet(lm=40, mm=60, nlay=2, dt_s=1.5)       # periodic in y
     f = read_input_data(p, files=files)
     with pytest.raises(capi.BeomError):                                   # too few rows per band
-        capi.MultiEngine(f, devices=[0] * 5)
+        capi.MultiEngine(f, devices=[0] * 11)
     with pytest.raises(capi.BeomError):                                   # RCCL wants one device per band
         capi.MultiEngine(f, devices=[0, 0], transport=capi.XCHG_RCCL)
     m = capi.MultiEngine(f, devices=[0])                                  # one band = the frame itself
