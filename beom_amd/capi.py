@@ -342,16 +342,18 @@ class Engine:
         return list(ms)[:7], list(nl)[:7]
 
     def field_tensors(self, names=("hlay", "u", "v", "h_u", "h_v")):
-        """Zero-copy torch views [nlay, ndeg+1] of the device-resident prognostic fields."""
+        """Zero-copy torch views [nlay, layer stride] of the device-resident prognostic fields.  Handles on the
+        table path keep the packed layout (layer stride ndeg+1); dense handles use a padded row pitch — cell
+        (i, j) at i + (j-1)*pitch (`self.row_pitch`) — so move rows with pack_rows/unpack_rows, not by slicing."""
         import torch
         out = {}
-        n1 = self.p.ndeg + 1
         cache = self.__dict__.setdefault("_tensor_cache", {})
         for k in names:
             ptr, sl, sr, r0 = C.c_void_p(), C.c_int64(), C.c_int64(), C.c_int64()
             self._check(self.lib.beom_device_field(self.h, k.encode(), C.byref(ptr), C.byref(sl),
                                                    C.byref(sr), C.byref(r0)))
-            assert sl.value == n1
+            n1 = sl.value
+            self.row_pitch = sr.value
             t = cache.get(ptr.value)          # the fused sweeps ping-pong buffers: key by address
             if t is None:
                 class _Iface:

@@ -19,6 +19,14 @@ struct DevView {
     int mm_glob;                  // mm of the whole frame (= mm unless the handle is a j-slab)
     long long n1;                 // ndeg + 1
     int L, M, xper, yper;         // dense closed form: L = lm+1, M = mm+1 (local rows)
+    // Dense handles keep every (0:ndeg) array with a PADDED row pitch on the device (invisible through the
+    // C-ABI: uploads scatter, downloads gather): cell (i, j) lives at i + (j-1)*P, P = L rounded up to 16
+    // doubles, and the arrays are placed so that index 1 is 128-byte aligned — every 64-cell tile row is then
+    // four whole cache lines (a tile row of the packed pitch lm+1 straddles five, and two workgroups write each
+    // shared line in part: tools/micro/march2.hip measures 3.9 vs 5.4 TB/s for the u+v sweep's shape).
+    // P = 0: packed layout (handles on the table path).  ncell = last cell index (P*M, or ndeg).
+    int P;
+    long long ncell;
     int joff, Mg, slab;           // j-slab: local row j is global row j + joff of Mg = mm_global+1 rows
     // rows a launch may WRITE: up to two strips [jlo, jhi] (local, inclusive); default one strip 1..M.
     // Used to split a step into an interior pass and an edge pass around the ghost-row exchange.
@@ -89,6 +97,19 @@ struct TileMap {
 };
 __host__ __device__ __forceinline__ bool row_selected(const DevView &d, int j) {
     return (j >= d.jlo0 && j <= d.jhi0) || (d.nstrip > 1 && j >= d.jlo1 && j <= d.jhi1);
+}
+
+// launches over ALL cell slots 0..d.ncell (stress, output scans, ...): false for the padding slots of the dense layout
+__device__ __forceinline__ bool cell_slot(const DevView &d, long long ip) {
+    if (ip > d.ncell) return false;
+    if (d.P == 0 || ip == 0) return true;
+    return (int)((ip - 1) % d.P) < d.L;
+}
+// 0-based packed index (the reference's ipnt - 1) of a real cell slot
+__device__ __forceinline__ long long packed_index0(const DevView &d, long long ip) {
+    if (d.P == 0) return ip - 1;
+    const long long r = (ip - 1) / d.P;
+    return r * d.L + ((ip - 1) - r * d.P);
 }
 
 // ---- cell contexts: where a thread is, who its neighbours are, what its masks are ----
@@ -183,27 +204,27 @@ struct CellDenseT {
     // lane l and lane l+1 of an INTERIOR wave hold cells (i, j) and (i+1, j): an east/west
     // neighbour value is one wavefront shuffle away instead of one more load
     static constexpr bool kLanesAreRowNeighbours = INTERIOR;
-    int i, j, ipnt, L, M, xper, yper;
+    int i, j, ipnt, L, M, P, xper, yper;
     int jg, Mg, ywrap;            // global row / row count (masks); y wrap only when not a slab
     static dim3 grid(const DevView &d, int nz) {
         return dim3(TileMap(d, BEOM_TILE_X, BEOM_TILE_Y).blocks(), (unsigned)nz, 1);
     }
     __device__ __forceinline__ bool init(const DevView &d) {
-        L = d.L; M = d.M; xper = d.xper; yper = d.yper;
+        L = d.L; M = d.M; P = d.P; xper = d.xper; yper = d.yper;
         const TileMap tm(d, BEOM_TILE_X, BEOM_TILE_Y);
         int ty, ch;
         if (!tm.locate(blockIdx.x, ty, ch)) return false;
         const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
         j = ty * BEOM_TILE_Y + wave / BEOM_TILE_WX + 1;
         i = ch * BEOM_TILE_X + (wave % BEOM_TILE_WX) * 64 + ((int)threadIdx.x & 63) + 1;
-        ipnt = i + (j - 1) * L;
+        ipnt = i + (j - 1) * P;
         jg = j + d.joff; Mg = d.Mg; ywrap = d.yper && !d.slab;
         return j <= M && i <= L && row_selected(d, j);
     }
     // context of an arbitrary LOCAL cell (a, b) of the same frame (used for halo cells)
     __device__ __forceinline__ void set_cell(const DevView &d, int a, int b) {
-        L = d.L; M = d.M; xper = d.xper; yper = d.yper;
-        i = a; j = b; ipnt = a + (b - 1) * L;
+        L = d.L; M = d.M; P = d.P; xper = d.xper; yper = d.yper;
+        i = a; j = b; ipnt = a + (b - 1) * P;
         jg = b + d.joff; Mg = d.Mg; ywrap = d.yper && !d.slab;
     }
     // wave-uniform: do all 64 cells of this wave satisfy 2 <= i <= L-2, 2 <= j <= M-2 ?
@@ -212,18 +233,18 @@ struct CellDenseT {
         return i0 >= 2 && i0 + 63 <= L - 2 && j >= 2 && j <= M - 2 && jg >= 2 && jg <= Mg - 2;
     }
     __device__ __forceinline__ CellDenseT<true> as_interior() const {
-        CellDenseT<true> r; r.i = i; r.j = j; r.ipnt = ipnt; r.L = L; r.M = M; r.xper = xper; r.yper = yper;
+        CellDenseT<true> r; r.i = i; r.j = j; r.ipnt = ipnt; r.L = L; r.M = M; r.P = P; r.xper = xper; r.yper = yper;
         r.jg = jg; r.Mg = Mg; r.ywrap = ywrap;
         return r;
     }
     __device__ __forceinline__ int at(int a, int b) const {     // a, b: LOCAL target coordinates
         if (xper) { if (a == 0) a = L - 1; else if (a == L) a = 1; }
         if (ywrap) { if (b == 0) b = M - 1; else if (b == M) b = 1; }
-        return (a >= 1 && a <= L && b >= 1 && b <= M) ? (a + (b - 1) * L) : 0;
+        return (a >= 1 && a <= L && b >= 1 && b <= M) ? (a + (b - 1) * P) : 0;
     }
     template <int K> __device__ __forceinline__ int nb() const {
         constexpr int di = NbOff<K>::di, dj = NbOff<K>::dj;
-        if (INTERIOR) return ipnt + di + dj * L;
+        if (INTERIOR) return ipnt + di + dj * P;
         return at(i + di, j + dj);
     }
     __device__ __forceinline__ static double f(bool c) { return c ? 1.0 : 0.0; }

@@ -38,15 +38,24 @@ void set_err(char *errm, int len, const char *fmt, ...) {
 
 }  // namespace
 
+struct StepTimer {        // optional HIP-event bracket around each kernel class
+    std::vector<hipEvent_t> ev; std::vector<int> cls;
+    hipStream_t st;
+    void begin(int c) { hipEvent_t a; (void)hipEventCreate(&a); (void)hipEventRecord(a, st); ev.push_back(a); cls.push_back(c); }
+    void end() { hipEvent_t b; (void)hipEventCreate(&b); (void)hipEventRecord(b, st); ev.push_back(b); }
+};
+
 struct beom_engine {
     beom_params P;
     int device = 0;
     hipStream_t stream = nullptr;      // stream in use (own_stream unless beom_set_stream)
     hipStream_t own_stream = nullptr;
-    struct StepTimer *timer = nullptr;  // non-null between beom_profile_start/stop
+    StepTimer *timer = nullptr;        // non-null between beom_profile_start/stop
     DevView d{};
     bool dense = false;
     std::vector<void *> allocs;
+    void *stage = nullptr;             // device image of ONE caller-layout slice [0:ndeg] (<= 32 B per cell) for uploads / downloads
+    size_t stage_bytes = 0;
     // geometry of the launches
     dim3 grid_cells0, grid_cells_layers_flat;
     bool wind = false, bot = false, top = false;
@@ -65,22 +74,59 @@ struct beom_engine {
 
 namespace {
 
+// Device arrays of doubles start 15 elements into their allocation so that cell index 1 is 128-byte
+// aligned (hipMalloc aligns to 256 B); see DevView::P.
 template <class T>
 int dev_alloc(beom_engine *E, T **p, size_t n, char *errm, int errm_len, bool zero = true) {
     void *q = nullptr;
-    HIP_TRY(hipMalloc(&q, n * sizeof(T)));
+    const size_t lead = sizeof(T) == 8 ? 15 : 0;
+    HIP_TRY(hipMalloc(&q, (n + lead + 1) * sizeof(T)));
     E->allocs.push_back(q);
-    if (zero) HIP_TRY(hipMemsetAsync(q, 0, n * sizeof(T), E->stream));
-    *p = (T *)q;
+    if (zero) HIP_TRY(hipMemsetAsync(q, 0, (n + lead + 1) * sizeof(T), E->stream));
+    *p = (T *)q + lead;
     return 0;
 }
 
+// one slice [0:ndeg][inner] (x K interleaved levels, level m) of a caller array <-> its device array
+template <class T, bool REMAP = false>
+int slice_to_device(beom_engine *E, T *dev, const T *host, int inner, int K, int m, char *errm, int errm_len) {
+    const DevView &d = E->d;
+    const size_t n = ((size_t)d.ndeg + 1) * inner * K;
+    if (n * sizeof(T) > E->stage_bytes) { set_err(errm, errm_len, "internal: staging buffer too small"); return -11; }
+    if (host) HIP_TRY(hipMemcpyAsync(E->stage, host, n * sizeof(T), hipMemcpyHostToDevice, E->stream));   // nullptr: the image is there already
+    const long long work = ((long long)d.ndeg + 1) * inner;
+    hipLaunchKernelGGL((k_repack<T, true, REMAP>), dim3((unsigned)((work + BEOM_BLOCK - 1) / BEOM_BLOCK)), dim3(BEOM_BLOCK), 0, E->stream,
+                       dev, (T *)E->stage, (long long)d.ndeg, d.L, d.P ? d.P : d.L, inner, K, m);
+    return 0;
+}
 template <class T>
-int dev_upload(beom_engine *E, const T **dst, const T *src, size_t n, char *errm, int errm_len) {
+int slice_to_host(beom_engine *E, const T *dev, T *host, int inner, int K, char *errm, int errm_len) {   // all K levels: dev[m]
+    (void)dev;
+    const DevView &d = E->d;
+    const size_t n = ((size_t)d.ndeg + 1) * inner * K;
+    HIP_TRY(hipMemcpyAsync(host, E->stage, n * sizeof(T), hipMemcpyDeviceToHost, E->stream));
+    HIP_TRY(hipStreamSynchronize(E->stream));
+    return 0;
+}
+template <class T>
+void slice_gather(beom_engine *E, const T *dev, int inner, int K, int m) {        // device array -> staging image (level m of K)
+    const DevView &d = E->d;
+    const long long work = ((long long)d.ndeg + 1) * inner;
+    hipLaunchKernelGGL((k_repack<T, false, false>), dim3((unsigned)((work + BEOM_BLOCK - 1) / BEOM_BLOCK)), dim3(BEOM_BLOCK), 0, E->stream,
+                       const_cast<T *>(dev), (T *)E->stage, (long long)d.ndeg, d.L, d.P ? d.P : d.L, inner, K, m);
+}
+
+// a static array [outer][0:ndeg][inner] of the caller -> a new device array; src == nullptr: zeros
+template <class T, bool REMAP = false>
+int dev_upload(beom_engine *E, const T **dst, const T *src, size_t outer, int inner, char *errm, int errm_len) {
+    const DevView &d = E->d;
     T *q = nullptr;
-    int rc = dev_alloc(E, &q, n, errm, errm_len, src == nullptr);
+    int rc = dev_alloc(E, &q, outer * (size_t)d.n1 * inner, errm, errm_len, true);
     if (rc) return rc;
-    if (src) HIP_TRY(hipMemcpyAsync(q, src, n * sizeof(T), hipMemcpyHostToDevice, E->stream));
+    const size_t n1h = (size_t)d.ndeg + 1;
+    if (src)
+        for (size_t o = 0; o < outer; ++o)
+            if ((rc = slice_to_device<T, REMAP>(E, q + o * (size_t)d.n1 * inner, src + o * n1h * inner, inner, 1, 0, errm, errm_len))) return rc;
     *dst = q;
     return 0;
 }
@@ -141,9 +187,9 @@ int beom_create(const beom_params *prm, int device, const int32_t *neig, const i
     HIP_TRY_E(hipStreamCreateWithFlags(&E->own_stream, hipStreamNonBlocking));
     E->stream = E->own_stream;
     DevView &d = E->d;
-    const size_t n1 = (size_t)prm->ndeg + 1, nl = (size_t)prm->nlay;
+    const size_t n1h = (size_t)prm->ndeg + 1, nl = (size_t)prm->nlay;      // n1h: cells per layer in the caller's arrays
     d.ndeg = prm->ndeg; d.nlay = prm->nlay; d.lm = prm->lm; d.mm = prm->mm; d.nsal = prm->nsal;
-    d.variant = prm->variant; d.n1 = (long long)n1;
+    d.variant = prm->variant; d.n1 = (long long)n1h;
     d.L = prm->lm + 1; d.M = prm->mm + 1;
     d.dl = prm->dl; d.dt = prm->dt; d.grav = prm->grav; d.rho0 = prm->rho0; d.beta = prm->beta;
     d.epsi = prm->epsi; d.gamm = prm->gamm; d.del1 = prm->del1; d.del2 = prm->del2; d.hmin = prm->hmin;
@@ -175,15 +221,32 @@ int beom_create(const beom_params *prm, int device, const int32_t *neig, const i
                 }
             }
     }
+    // device layout: padded row pitch for dense frames (DevView::P), the caller's packed layout otherwise
+    d.P = 0; d.ncell = prm->ndeg;
+    if (E->dense) {
+        d.P = getenv("BEOM_NO_PITCH") ? d.L : (d.L + 15) / 16 * 16;      // (BEOM_NO_PITCH: the packed pitch, for A/B measurements)
+        d.ncell = (long long)d.P * d.M;
+        d.n1 = (d.ncell + 1 + 15) / 16 * 16;
+    }
+    const size_t n1 = (size_t)d.n1;                   // cells per layer on the device
     int rc = 0;
-#define UP(name, src, n) if ((rc = dev_upload(E, &d.name, src, (size_t)(n), errm, errm_len))) { beom_destroy(E); return rc; }
-    UP(neig, neig, 8 * n1) UP(subc, subc, 2 * n1)
-    UP(mk_u, mk_u, n1) UP(mk_v, mk_v, n1) UP(mk_n, mk_n, n1) UP(mkpe, mkpe, n1) UP(mkpi, mkpi, n1)
-    UP(fcor, fcor, n1) UP(h_th, h_th, n1) UP(h_to, h_to, n1)
-    UP(nudg, nudg, 3 * n1) UP(fnud, fnud, 3 * nl * n1) UP(hdot, hdot, nl * n1)
-    UP(tide, tide, 6 * n1) UP(bodf, bodf, 2 * nl) UP(taus, taus, 2 * n1)
+    E->stage_bytes = n1h * 32;                        // the widest slice: neig (8 x int32), a history (3 doubles)
+    HIP_TRY_E(hipMalloc(&E->stage, E->stage_bytes));
+#define UP(name, src, outer, inner) if ((rc = dev_upload(E, &d.name, src, (size_t)(outer), (inner), errm, errm_len))) { beom_destroy(E); return rc; }
+    if ((rc = dev_upload<int32_t, true>(E, &d.neig, neig, 1, 8, errm, errm_len))) { beom_destroy(E); return rc; }
+    UP(subc, subc, 2, 1)
+    UP(mk_u, mk_u, 1, 1) UP(mk_v, mk_v, 1, 1) UP(mk_n, mk_n, 1, 1) UP(mkpe, mkpe, 1, 1) UP(mkpi, mkpi, 1, 1)
+    UP(fcor, fcor, 1, 1) UP(h_th, h_th, 1, 1) UP(h_to, h_to, 1, 1)
+    UP(nudg, nudg, 3, 1) UP(fnud, fnud, 3 * nl, 1) UP(hdot, hdot, nl, 1)
+    UP(tide, tide, 3, 2) UP(taus, taus, 2, 1)
 #undef UP
-    for (size_t i = 0; i < n1; ++i) { if (mk_u[i] > 0.5) E->any_u = 1; if (mk_v[i] > 0.5) E->any_v = 1; }
+    {   // bodf(nlay, 2): no cell dimension
+        double *q = nullptr;
+        if ((rc = dev_alloc(E, &q, 2 * nl, errm, errm_len, true))) { beom_destroy(E); return rc; }
+        if (bodf) HIP_TRY_E(hipMemcpyAsync(q, bodf, 2 * nl * sizeof(double), hipMemcpyHostToDevice, E->stream));
+        d.bodf = q;
+    }
+    for (size_t i = 0; i < n1h; ++i) { if (mk_u[i] > 0.5) E->any_u = 1; if (mk_v[i] > 0.5) E->any_v = 1; }
     d.woff = nullptr;
     if (!E->dense && getenv("BEOM_NO_WAVE_TABLE") == nullptr) {      // table path: which runs of 64 cells are uniform interior?
         const long long nw = ((long long)prm->ndeg + 63) / 64;
@@ -206,18 +269,24 @@ int beom_create(const beom_params *prm, int device, const int32_t *neig, const i
             if (ok) { woff[2 * w] = dN; woff[2 * w + 1] = dS; ++nuni; }
         }
         E->uniform_waves = nuni; E->total_waves = nw;
-        if (nuni > 0 && (rc = dev_upload(E, &d.woff, woff.data(), (size_t)(2 * nw), errm, errm_len))) { beom_destroy(E); return rc; }
+        if (nuni > 0) {      // (table path: packed layout, no repacking)
+            int32_t *q = nullptr;
+            if ((rc = dev_alloc(E, &q, (size_t)(2 * nw), errm, errm_len, false))) { beom_destroy(E); return rc; }
+            HIP_TRY_E(hipMemcpyAsync(q, woff.data(), (size_t)(2 * nw) * sizeof(int32_t), hipMemcpyHostToDevice, E->stream));
+            HIP_TRY_E(hipStreamSynchronize(E->stream));
+            d.woff = q;
+        }
     }
-    d.has_hdot = any_nonzero(hdot, nl * n1);
-    d.has_tide = any_nonzero(tide, 6 * n1);
+    d.has_hdot = any_nonzero(hdot, nl * n1h);
+    d.has_tide = any_nonzero(tide, 6 * n1h);
     d.has_bodf = any_nonzero(bodf, 2 * nl);
-    d.has_nudg = any_nonzero(nudg, 3 * n1);
-    d.has_hto = any_nonzero(h_to, n1);
+    d.has_nudg = any_nonzero(nudg, 3 * n1h);
+    d.has_hto = any_nonzero(h_to, n1h);
     d.keep_diag = 0; d.lean_d2h = 0; E->lean_d2h = true;
     E->fuse = getenv("BEOM_NO_FUSE") == nullptr;
     E->fuse_uv = getenv("BEOM_NO_FUSE") == nullptr && getenv("BEOM_NO_FUSE_UV") == nullptr;
     E->wind = false;
-    if (taus) for (size_t i = 0; i < 2 * n1; ++i) if (std::fabs(taus[i]) > 1.e-7) { E->wind = true; break; }   // :1945
+    if (taus) for (size_t i = 0; i < 2 * n1h; ++i) if (std::fabs(taus[i]) > 1.e-7) { E->wind = true; break; }   // :1945
     E->bot = prm->bdrg > 1.e-7;                                                                                  // :1969
     E->top = prm->tdrg > 1.e-7;                                                                                  // :1991
     d.has_wind = E->wind;
@@ -242,13 +311,13 @@ int beom_create(const beom_params *prm, int device, const int32_t *neig, const i
 #undef AL
     // initialize_variables: v_cc = v_ll = bvis everywhere, sentinel included (:276-277)
     if (prm->bvis != 0.0) {
-        std::vector<double> b(nl * n1, prm->bvis);
+        std::vector<double> b(nl * n1, prm->bvis);      // (padding slots too: never read)
         HIP_TRY_E(hipMemcpyAsync(d.v_cc, b.data(), b.size() * sizeof(double), hipMemcpyHostToDevice, E->stream));
         HIP_TRY_E(hipMemcpyAsync(d.v_ll, b.data(), b.size() * sizeof(double), hipMemcpyHostToDevice, E->stream));
         HIP_TRY_E(hipStreamSynchronize(E->stream));
     }
-    const unsigned gx = (unsigned)((prm->ndeg + BEOM_BLOCK - 1) / BEOM_BLOCK);
-    const unsigned gx0 = (unsigned)((prm->ndeg + 1 + BEOM_BLOCK - 1) / BEOM_BLOCK);
+    const unsigned gx = (unsigned)((d.ncell + BEOM_BLOCK - 1) / BEOM_BLOCK);          // launches over all cell slots
+    const unsigned gx0 = (unsigned)((d.ncell + 1 + BEOM_BLOCK - 1) / BEOM_BLOCK);
     E->grid_cells_layers_flat = dim3(gx, (unsigned)prm->nlay, 1);
     E->grid_cells0 = dim3(gx0, 1, 1);
     HIP_TRY_E(hipStreamSynchronize(E->stream));
@@ -262,43 +331,54 @@ int beom_destroy(beom_handle E) {
     (void)hipSetDevice(E->device);
     if (E->stream) (void)hipStreamSynchronize(E->stream);
     for (void *p : E->allocs) (void)hipFree(p);
+    if (E->stage) (void)hipFree(E->stage);
+    if (E->timer) { for (hipEvent_t ev : E->timer->ev) (void)hipEventDestroy(ev); delete E->timer; }
     if (E->own_stream) (void)hipStreamDestroy(E->own_stream);
     delete E;
     return 0;
 }
 
 // ---- host <-> device copies with the Fortran layouts ------------------------------
-static int copy_in(beom_engine *E, double *dst, const double *src, size_t n, char *errm, int errm_len) {
+// [outer][0:ndeg] arrays of the caller (outer = nlay, or 2*nlay for the stresses), slice by slice
+static int copy_in(beom_engine *E, double *dst, const double *src, size_t outer, char *errm, int errm_len) {
     if (!src) return 0;
-    HIP_TRY(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyHostToDevice, E->stream));
+    const size_t n1h = (size_t)E->d.ndeg + 1;
+    for (size_t o = 0; o < outer; ++o) {
+        const int rc = slice_to_device<double>(E, dst + o * (size_t)E->d.n1, src + o * n1h, 1, 1, 0, errm, errm_len);
+        if (rc) return rc;
+    }
     return 0;
 }
-static int copy_out(beom_engine *E, double *dst, const double *src, size_t n, char *errm, int errm_len) {
+static int copy_out(beom_engine *E, double *dst, const double *src, size_t outer, char *errm, int errm_len) {
     if (!dst) return 0;
-    HIP_TRY(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToHost, E->stream));
+    const size_t n1h = (size_t)E->d.ndeg + 1;
+    for (size_t o = 0; o < outer; ++o) {
+        slice_gather<double>(E, src + o * (size_t)E->d.n1, 1, 1, 0);
+        const int rc = slice_to_host<double>(E, src, dst + o * n1h, 1, 1, errm, errm_len);
+        if (rc) return rc;
+    }
     return 0;
 }
 
-// AoS history (m, 0:ndeg, nlay) <-> K separate (0:ndeg, nlay) device arrays
+// AoS history (m, 0:ndeg, nlay) <-> K separate (0:ndeg, nlay) device arrays, layer by layer
 static int hist_in(beom_engine *E, double *const *dev, int K, const double *src, char *errm, int errm_len) {
     if (!src) return 0;
-    const size_t n = (size_t)E->d.n1 * E->d.nlay;
-    std::vector<double> tmp(n);
-    for (int m = 0; m < K; ++m) {
-        for (size_t i = 0; i < n; ++i) tmp[i] = src[m + (size_t)K * i];
-        HIP_TRY(hipMemcpyAsync(dev[m], tmp.data(), n * sizeof(double), hipMemcpyHostToDevice, E->stream));
-        HIP_TRY(hipStreamSynchronize(E->stream));
-    }
+    const size_t n1h = (size_t)E->d.ndeg + 1;
+    for (int l = 0; l < E->d.nlay; ++l)
+        for (int m = 0; m < K; ++m) {       // the layer's image is uploaded once, then one scatter per level
+            const int rc = slice_to_device<double>(E, dev[m] + (size_t)l * E->d.n1, m == 0 ? src + (size_t)l * n1h * K : nullptr, 1, K, m,
+                                                   errm, errm_len);
+            if (rc) return rc;
+        }
     return 0;
 }
 static int hist_out(beom_engine *E, double *const *dev, int K, double *dst, char *errm, int errm_len) {
     if (!dst) return 0;
-    const size_t n = (size_t)E->d.n1 * E->d.nlay;
-    std::vector<double> tmp(n);
-    for (int m = 0; m < K; ++m) {
-        HIP_TRY(hipMemcpyAsync(tmp.data(), dev[m], n * sizeof(double), hipMemcpyDeviceToHost, E->stream));
-        HIP_TRY(hipStreamSynchronize(E->stream));
-        for (size_t i = 0; i < n; ++i) dst[m + (size_t)K * i] = tmp[i];
+    const size_t n1h = (size_t)E->d.ndeg + 1;
+    for (int l = 0; l < E->d.nlay; ++l) {
+        for (int m = 0; m < K; ++m) slice_gather<double>(E, dev[m] + (size_t)l * E->d.n1, 1, K, m);
+        const int rc = slice_to_host<double>(E, dev[0], dst + (size_t)l * n1h * K, 1, K, errm, errm_len);
+        if (rc) return rc;
     }
     return 0;
 }
@@ -310,18 +390,18 @@ int beom_upload_state(beom_handle E, const double *hlay, const double *u, const 
     if (!E) { set_err(errm, errm_len, "null handle"); return -1; }
     HIP_TRY(hipSetDevice(E->device));
     DevView &d = E->d;
-    const size_t n = (size_t)d.n1 * d.nlay;
+    const size_t nl = (size_t)d.nlay, n = ((size_t)d.ndeg + 1) * nl;
     int rc;
-    if ((rc = copy_in(E, d.hlay, hlay, n, errm, errm_len))) return rc;
-    if ((rc = copy_in(E, d.u, u, n, errm, errm_len))) return rc;
-    if ((rc = copy_in(E, d.v, v, n, errm, errm_len))) return rc;
-    if ((rc = copy_in(E, d.h_u, h_u, n, errm, errm_len))) return rc;
-    if ((rc = copy_in(E, d.h_v, h_v, n, errm, errm_len))) return rc;
-    if ((rc = copy_in(E, d.v_cc, v_cc, n, errm, errm_len))) return rc;
-    if ((rc = copy_in(E, d.v_ll, v_ll, n, errm, errm_len))) return rc;
-    if ((rc = copy_in(E, d.tt3d, tt3d, 2 * n, errm, errm_len))) return rc;
-    if ((rc = copy_in(E, d.tb3d, tb3d, 2 * n, errm, errm_len))) return rc;
-    if ((rc = copy_in(E, d.tu3d, tu3d, 2 * n, errm, errm_len))) return rc;
+    if ((rc = copy_in(E, d.hlay, hlay, nl, errm, errm_len))) return rc;
+    if ((rc = copy_in(E, d.u, u, nl, errm, errm_len))) return rc;
+    if ((rc = copy_in(E, d.v, v, nl, errm, errm_len))) return rc;
+    if ((rc = copy_in(E, d.h_u, h_u, nl, errm, errm_len))) return rc;
+    if ((rc = copy_in(E, d.h_v, h_v, nl, errm, errm_len))) return rc;
+    if ((rc = copy_in(E, d.v_cc, v_cc, nl, errm, errm_len))) return rc;
+    if ((rc = copy_in(E, d.v_ll, v_ll, nl, errm, errm_len))) return rc;
+    if ((rc = copy_in(E, d.tt3d, tt3d, 2 * nl, errm, errm_len))) return rc;
+    if ((rc = copy_in(E, d.tb3d, tb3d, 2 * nl, errm, errm_len))) return rc;
+    if ((rc = copy_in(E, d.tu3d, tu3d, 2 * nl, errm, errm_len))) return rc;
     if ((rc = hist_in(E, d.rs, 2, rs_h, errm, errm_len))) return rc;
     if ((rc = hist_in(E, d.dmx, 3, dmdx, errm, errm_len))) return rc;
     if ((rc = hist_in(E, d.dmy, 3, dmdy, errm, errm_len))) return rc;
@@ -331,6 +411,7 @@ int beom_upload_state(beom_handle E, const double *hlay, const double *u, const 
     for (const double *a : {v_cc, v_ll})
         if (a) for (size_t i = 0; i < n && E->visc_all_zero; ++i) { uint64_t b; memcpy(&b, &a[i], 8); if (b != 0) E->visc_all_zero = false; }
     HIP_TRY(hipStreamSynchronize(E->stream));
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 
@@ -340,22 +421,23 @@ int beom_download_state(beom_handle E, double *hlay, double *u, double *v, doubl
     if (!E) { set_err(errm, errm_len, "null handle"); return -1; }
     HIP_TRY(hipSetDevice(E->device));
     DevView &d = E->d;
-    const size_t n = (size_t)d.n1 * d.nlay;
+    const size_t nl = (size_t)d.nlay;
     int rc;
-    if ((rc = copy_out(E, hlay, d.hlay, n, errm, errm_len))) return rc;
-    if ((rc = copy_out(E, u, d.u, n, errm, errm_len))) return rc;
-    if ((rc = copy_out(E, v, d.v, n, errm, errm_len))) return rc;
-    if ((rc = copy_out(E, h_u, d.h_u, n, errm, errm_len))) return rc;
-    if ((rc = copy_out(E, h_v, d.h_v, n, errm, errm_len))) return rc;
-    if ((rc = copy_out(E, v_cc, d.v_cc, n, errm, errm_len))) return rc;
-    if ((rc = copy_out(E, v_ll, d.v_ll, n, errm, errm_len))) return rc;
-    if ((rc = copy_out(E, tt3d, d.tt3d, 2 * n, errm, errm_len))) return rc;
-    if ((rc = copy_out(E, tb3d, d.tb3d, 2 * n, errm, errm_len))) return rc;
-    if ((rc = copy_out(E, tu3d, d.tu3d, 2 * n, errm, errm_len))) return rc;
-    HIP_TRY(hipStreamSynchronize(E->stream));
+    if ((rc = copy_out(E, hlay, d.hlay, nl, errm, errm_len))) return rc;
+    if ((rc = copy_out(E, u, d.u, nl, errm, errm_len))) return rc;
+    if ((rc = copy_out(E, v, d.v, nl, errm, errm_len))) return rc;
+    if ((rc = copy_out(E, h_u, d.h_u, nl, errm, errm_len))) return rc;
+    if ((rc = copy_out(E, h_v, d.h_v, nl, errm, errm_len))) return rc;
+    if ((rc = copy_out(E, v_cc, d.v_cc, nl, errm, errm_len))) return rc;
+    if ((rc = copy_out(E, v_ll, d.v_ll, nl, errm, errm_len))) return rc;
+    if ((rc = copy_out(E, tt3d, d.tt3d, 2 * nl, errm, errm_len))) return rc;
+    if ((rc = copy_out(E, tb3d, d.tb3d, 2 * nl, errm, errm_len))) return rc;
+    if ((rc = copy_out(E, tu3d, d.tu3d, 2 * nl, errm, errm_len))) return rc;
     if ((rc = hist_out(E, d.rs, 2, rs_h, errm, errm_len))) return rc;
     if ((rc = hist_out(E, d.dmx, 3, dmdx, errm, errm_len))) return rc;
     if ((rc = hist_out(E, d.dmy, 3, dmdy, errm, errm_len))) return rc;
+    HIP_TRY(hipStreamSynchronize(E->stream));
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 
@@ -364,14 +446,14 @@ int beom_download_scratch(beom_handle E, double *mont, double *rvor, double *pvo
     if (!E) { set_err(errm, errm_len, "null handle"); return -1; }
     HIP_TRY(hipSetDevice(E->device));
     DevView &d = E->d;
-    const size_t n = (size_t)d.n1 * d.nlay;
+    const size_t nl = (size_t)d.nlay;
     int rc;
-    if ((rc = copy_out(E, mont, d.mont, n, errm, errm_len))) return rc;
-    if ((rc = copy_out(E, rvor, d.rvor, n, errm, errm_len))) return rc;
-    if ((rc = copy_out(E, pvor, d.pvor, n, errm, errm_len))) return rc;
-    if ((rc = copy_out(E, dive, d.dive, n, errm, errm_len))) return rc;
-    if ((rc = copy_out(E, d2hx, d.d2hx, n, errm, errm_len))) return rc;
-    if ((rc = copy_out(E, d2hy, d.d2hy, n, errm, errm_len))) return rc;
+    if ((rc = copy_out(E, mont, d.mont, nl, errm, errm_len))) return rc;
+    if ((rc = copy_out(E, rvor, d.rvor, nl, errm, errm_len))) return rc;
+    if ((rc = copy_out(E, pvor, d.pvor, nl, errm, errm_len))) return rc;
+    if ((rc = copy_out(E, dive, d.dive, nl, errm, errm_len))) return rc;
+    if ((rc = copy_out(E, d2hx, d.d2hx, nl, errm, errm_len))) return rc;
+    if ((rc = copy_out(E, d2hy, d.d2hy, nl, errm, errm_len))) return rc;
     HIP_TRY(hipStreamSynchronize(E->stream));
     return 0;
 }
@@ -545,13 +627,6 @@ static StepScalars step_scalars(const beom_engine *E, int tstp, double tres, dou
     s.fused_uv = E->dense && E->fuse_uv && !(E->P.svis > 0.0);
     return s;
 }
-
-struct StepTimer {        // optional HIP-event bracket around each kernel class
-    std::vector<hipEvent_t> ev; std::vector<int> cls;
-    hipStream_t st;
-    void begin(int c) { hipEvent_t a; (void)hipEventCreate(&a); (void)hipEventRecord(a, st); ev.push_back(a); cls.push_back(c); }
-    void end() { hipEvent_t b; (void)hipEventCreate(&b); (void)hipEventRecord(b, st); ev.push_back(b); }
-};
 
 static void one_step(beom_engine *E, int tstp, const StepScalars &s) {
     StepTimer *T = E->timer;
@@ -746,7 +821,7 @@ int beom_download_outputs(beom_handle E, const float *h0r4, float *eta, float *u
         E->allocs.push_back(E->scan_dev);
     }
     if (h0r4) HIP_TRY(hipMemcpyAsync(E->h0r4_dev, h0r4, n * sizeof(float), hipMemcpyHostToDevice, E->stream));
-    const unsigned gx = (unsigned)((d.ndeg + BEOM_BLOCK - 1) / BEOM_BLOCK);
+    const unsigned gx = (unsigned)((d.ncell + BEOM_BLOCK - 1) / BEOM_BLOCK);
     if (eta || u4 || v4) {
         hipLaunchKernelGGL(k_out_convert, dim3(gx), dim3(BEOM_BLOCK), 0, E->stream, d, E->h0r4_dev,
                            eta ? E->out4[0] : nullptr, u4 ? E->out4[1] : nullptr, v4 ? E->out4[2] : nullptr);
@@ -804,10 +879,18 @@ int beom_set_open_boundaries(beom_handle E, int nseg, const int32_t *segm, char 
         for (long long r : rd)
             if (std::binary_search(w2.begin(), w2.end(), r)) { set_err(errm, errm_len, "beom_set_open_boundaries: a segment reads a point another segment updates in the same pass (serial order would matter)"); return -7; }
     }
+    // columns 1, 7, 10, 13, 16 are cell indices: to the device pitch
+    std::vector<int32_t> sg(segm, segm + (size_t)nseg * 18);
+    if (E->d.P)
+        for (int col : {1, 7, 10, 13, 16})
+            for (int is = 0; is < nseg; ++is) {
+                int32_t &q = sg[(size_t)is + (size_t)nseg * (col - 1)];
+                if (q > 0) q = (int32_t)(1 + (long long)((q - 1) / E->d.L) * E->d.P + (q - 1) % E->d.L);
+            }
     int32_t *dev = nullptr;
     HIP_TRY(hipMalloc((void **)&dev, (size_t)nseg * 18 * sizeof(int32_t)));
     E->allocs.push_back(dev);
-    HIP_TRY(hipMemcpy(dev, segm, (size_t)nseg * 18 * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dev, sg.data(), (size_t)nseg * 18 * sizeof(int32_t), hipMemcpyHostToDevice));
     E->d.segm = dev;
     E->d.nseg = nseg;
     E->obc = E->P.flag_nudging && E->P.mcbc < 0.5;
@@ -848,7 +931,7 @@ int beom_device_field(beom_handle E, const char *name, void **dptr, int64_t *str
     else return -3;
     *dptr = p;
     if (stride_layer) *stride_layer = d.n1;
-    if (stride_row) *stride_row = E->dense ? d.L : 0;
+    if (stride_row) *stride_row = d.P ? d.P : (E->dense ? d.L : 0);
     if (row0_offset) *row0_offset = 1;
     return 0;
 }

@@ -344,7 +344,7 @@ __device__ __forceinline__ void body_mont_visc(const DevView &d, int x0, int y0,
             if (!ok[q]) widx[q] = 0;                   // beyond the frame: lookups give the sentinel
             else if ((d.xper && i == d.L) || (d.yper && !d.slab && j == d.M)) {
                 int a = i, b = j;
-                widx[q] = halo_target<INT>(d, a, b) ? a + (b - 1) * d.L : 0;
+                widx[q] = halo_target<INT>(d, a, b) ? a + (b - 1) * d.P : 0;
             }
         }
     }
@@ -847,7 +847,7 @@ __device__ __forceinline__ void body_uv_fused_staged(const DevView &d, int x0, i
         const int idx = tid + k * UV_BLOCK;
         const int idc = idx < NST ? idx : tid;           // clamped: the load is harmless, the store is skipped
         frr[k] = idc / (UV_TX + 2); fcc[k] = idc - frr[k] * (UV_TX + 2);
-        const long long ip = (long long)(x0 - 1 + fcc[k]) + (long long)(y0 - 2 + frr[k]) * d.L + lay;
+        const long long ip = (long long)(x0 - 1 + fcc[k]) + (long long)(y0 - 2 + frr[k]) * d.P + lay;
 #pragma unroll
         for (int f = 0; f < 5; ++f) if (f >= NF && f < 4) fv[k][f] = 0.0; else fv[k][f] = src[f][ip];
     }
@@ -858,7 +858,7 @@ __device__ __forceinline__ void body_uv_fused_staged(const DevView &d, int x0, i
     else if (tid < 2 * (UV_TX + 2)) { hrr = UV_HROWS - 1; hcc = 1 + tid - (UV_TX + 2); }
     else if (tid < 2 * (UV_TX + 2) + UV_SROWS) { hrr = 1 + tid - 2 * (UV_TX + 2); hcc = 0; }
     else if (tid < 2 * (UV_TX + 2) + 2 * UV_SROWS) { hrr = 1 + tid - 2 * (UV_TX + 2) - UV_SROWS; hcc = UV_HLDX - 1; }
-    const double hring = d.hlay[(long long)(x0 - 2 + (hrr >= 0 ? hcc : 2)) + (long long)(y0 - 3 + (hrr >= 0 ? hrr : 2)) * d.L + lay];
+    const double hring = d.hlay[(long long)(x0 - 2 + (hrr >= 0 ? hcc : 2)) + (long long)(y0 - 3 + (hrr >= 0 ? hrr : 2)) * d.P + lay];
     CellDenseT<true> c[UV_Q];
     bool wr[UV_Q];
     double pre[UV_Q][8];
@@ -1021,7 +1021,7 @@ static inline dim3 uv_fused_grid(const DevView &d) {
 // (a) layer fractions layt/layb/layu, cells 0..ndeg (the sentinel included, :1948,1972,1994)
 __global__ __launch_bounds__(BEOM_BLOCK) void k_stress_fractions(DevView d, int wind, int bot, int top) {
     const int ipnt = blockIdx.x * BEOM_BLOCK + threadIdx.x;     // 0..ndeg
-    if (ipnt > d.ndeg) return;
+    if (!cell_slot(d, ipnt)) return;
     const int nlay = d.nlay;
     if (wind || top) {
         for (int pass = 0; pass < 2; ++pass) {
@@ -1062,7 +1062,7 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_stress_fractions(DevView d, int 
 //     (runs once per n_3d steps and needs the sentinel cell: always via the neig table)
 __global__ __launch_bounds__(BEOM_BLOCK) void k_stress_tau(DevView d, int pass) {
     const int ipnt = blockIdx.x * BEOM_BLOCK + threadIdx.x;     // 0..ndeg
-    if (ipnt > d.ndeg) return;
+    if (!cell_slot(d, ipnt)) return;
     const int nlay = d.nlay;
     int ilay = pass == 0 ? nlay : 1;
     if (d.ocrp > 0.5) {
@@ -1088,7 +1088,7 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_stress_tau(DevView d, int pass) 
 __global__ __launch_bounds__(BEOM_BLOCK) void k_stress_apply(DevView d, int wind, int bot, int top) {
     const int ipnt = blockIdx.x * BEOM_BLOCK + threadIdx.x + 1;
     const int ilay = blockIdx.y + 1;
-    if (ipnt > d.ndeg) return;
+    if (!cell_slot(d, ipnt)) return;
     const int c5 = d.neig[8ll * ipnt + 4], c7 = d.neig[8ll * ipnt + 6];
     if (bot) {
         T3_(d.tb3d, ipnt, 1, ilay) = d.taub[ipnt] * 0.5 * (LL(d.layb, ipnt, ilay) + LL(d.layb, c5, ilay));
@@ -1101,6 +1101,27 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_stress_apply(DevView d, int wind
     if (wind) {
         T3_(d.tt3d, ipnt, 1, ilay) = d.taus[ipnt] * LL(d.layt, ipnt, ilay);
         T3_(d.tt3d, ipnt, 2, ilay) = d.taus[ipnt + d.n1] * LL(d.layt, ipnt, ilay);
+    }
+}
+
+// ---- packed (the caller's Fortran storage) <-> padded device layout, one slice [0:ndeg] at a time ----
+// src/dst element = `inner` consecutive T; AoS histories: K interleaved levels, level m selected.
+// REMAP: the values themselves are cell indices (neig): translate them too.
+template <class T, bool TO_DEVICE, bool REMAP>
+__global__ __launch_bounds__(BEOM_BLOCK) void k_repack(T *dev, T *host_img, long long ndeg, int L, int P, int inner, int K, int m) {
+    const long long t = (long long)blockIdx.x * BEOM_BLOCK + threadIdx.x;
+    const long long n = (ndeg + 1) * inner;
+    if (t >= n) return;
+    const long long ip = t / inner;
+    const int e = (int)(t - ip * inner);
+    long long dp = ip;
+    if (ip > 0) { const long long r = (ip - 1) / L; dp = 1 + r * P + ((ip - 1) - r * L); }
+    if (TO_DEVICE) {
+        T v = host_img[(ip * inner + e) * K + m];
+        if (REMAP) { const long long q = (long long)v; if (q > 0) { const long long r = (q - 1) / L; v = (T)(1 + r * P + ((q - 1) - r * L)); } }
+        dev[dp * inner + e] = v;
+    } else {
+        host_img[(ip * inner + e) * K + m] = dev[dp * inner + e];
     }
 }
 
@@ -1117,7 +1138,8 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_rows_copy(DevView d, int jlo, in
     const int lay = (int)(r / per_lay);
     const long long c = r - (long long)lay * per_lay;
     double *fld = f == 0 ? d.hlay : f == 1 ? d.u : f == 2 ? d.v : f == 3 ? d.h_u : d.h_v;
-    const long long ip = 1 + (long long)(jlo - 1) * d.L + c + d.n1 * (long long)lay;
+    const long long row = c / d.L;
+    const long long ip = 1 + (long long)(jlo - 1 + row) * (d.P ? d.P : d.L) + (c - row * d.L) + d.n1 * (long long)lay;
     if (PACK) buf[t] = fld[ip];
     else fld[ip] = buf[t];
 }
@@ -1129,11 +1151,11 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_rows_copy(DevView d, int jlo, in
 __global__ __launch_bounds__(BEOM_BLOCK) void k_out_convert(DevView d, const float *h0r4, float *eta, float *u4,
                                                             float *v4) {
     const int ipnt = blockIdx.x * BEOM_BLOCK + threadIdx.x + 1;
-    if (ipnt > d.ndeg) return;
-    const long long nd = d.ndeg;
+    if (!cell_slot(d, ipnt)) return;
+    const long long nd = d.ndeg, pk = packed_index0(d, ipnt);     // the records are packed (ndeg, nlay) whatever the device pitch
     float acc = 0.f;
     for (int k = d.nlay; k >= 1; --k) {
-        const long long o = (long long)(ipnt - 1) + nd * (k - 1);
+        const long long o = pk + nd * (k - 1);
         const double h = LL(d.hlay, ipnt, k) - (double)h0r4[o];
         acc = (k == d.nlay) ? (float)h : (float)(h + (double)acc);
         if (eta) eta[o] = acc;
@@ -1148,7 +1170,7 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_out_convert(DevView d, const flo
 __global__ __launch_bounds__(BEOM_BLOCK) void k_out_scan(DevView d, int any_u, int any_v, double *out) {
     __shared__ double red[BEOM_BLOCK / 64][7];
     const int ipnt = blockIdx.x * BEOM_BLOCK + threadIdx.x;          // 0..ndeg
-    const bool in = ipnt <= d.ndeg;
+    const bool in = cell_slot(d, ipnt);
     const double big = 1.7976931348623157e308;
     for (int k = 1; k <= d.nlay; ++k) {
         double v[7] = {big, -big, big, -big, big, -big, 0.0};
@@ -1220,7 +1242,7 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_no_gradient_obc(DevView d, int p
 __global__ __launch_bounds__(BEOM_BLOCK) void k_biharm_lap(DevView d, int ilay0) {             // :2508-2550
     const int ipnt = blockIdx.x * BEOM_BLOCK + threadIdx.x + 1;
     const int ilay = ilay0 ? ilay0 : (int)blockIdx.y + 1;
-    if (ipnt > d.ndeg) return;
+    if (!cell_slot(d, ipnt)) return;
     const int32_t *nb = d.neig + 8ll * ipnt;
     const int c1 = nb[0], c3 = nb[2], c5 = nb[4], c7 = nb[6];
     const double dl = d.dl;
@@ -1241,7 +1263,7 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_biharm_lap(DevView d, int ilay0)
 __global__ __launch_bounds__(BEOM_BLOCK) void k_biharm_flux(DevView d, int ilay0) {            // :2557-2598
     const int ipnt = blockIdx.x * BEOM_BLOCK + threadIdx.x + 1;
     const int ilay = ilay0 ? ilay0 : (int)blockIdx.y + 1;
-    if (ipnt > d.ndeg) return;
+    if (!cell_slot(d, ipnt)) return;
     const int32_t *nb = d.neig + 8ll * ipnt;
     const int c1 = nb[0], c3 = nb[2], c5 = nb[4], c6 = nb[5], c7 = nb[6];
     const double dl = d.dl;

@@ -481,12 +481,21 @@ class SlabRunner:
         """Companion frame: refresh its rows 1..6 and mm-3..mm from this band (its first owned rows and
         its south ghosts, as they stand BEFORE step t), then its own step t."""
         g, L, G = self.g, self.g.L, GHOST
-        mt = self.mini.field_tensors(EXCHANGED)
-        bt = self.t
-        lo_a, lo_b = 1 + g.ghost_s * L, 1 + (g.ghost_s + MINI_LO) * L
-        for k in EXCHANGED:
-            mt[k][:, 1:1 + MINI_LO * L].copy_(bt[k][:, lo_a:lo_b])
-            mt[k][:, 1 + MINI_LO * L:1 + (MINI_LO + G) * L].copy_(bt[k][:, 1:1 + G * L])
+        if self.fast_pack:            # device handles: the row pitch is the library's business
+            if not hasattr(self, "_mini_buf"):
+                ref = self.send_s
+                self._mini_buf = self.torch.empty(len(EXCHANGED) * self.nlay * MINI_LO * L, dtype=ref.dtype, device=ref.device)
+            self.engine.pack_rows(g.ghost_s + 1, MINI_LO, self._mini_buf)
+            self.mini.unpack_rows(1, MINI_LO, self._mini_buf)
+            self.engine.pack_rows(1, G, self._mini_buf)
+            self.mini.unpack_rows(MINI_LO + 1, G, self._mini_buf)
+        else:
+            mt = self.mini.field_tensors(EXCHANGED)
+            bt = self.t
+            lo_a, lo_b = 1 + g.ghost_s * L, 1 + (g.ghost_s + MINI_LO) * L
+            for k in EXCHANGED:
+                mt[k][:, 1:1 + MINI_LO * L].copy_(bt[k][:, lo_a:lo_b])
+                mt[k][:, 1 + MINI_LO * L:1 + (MINI_LO + G) * L].copy_(bt[k][:, 1:1 + G * L])
         self.mini.step(t, 1, sync=False)
 
     def exchange(self):
