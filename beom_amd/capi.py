@@ -339,7 +339,7 @@ class Engine:
         ms = (C.c_double * 8)()
         nl = (C.c_int * 8)()
         self._check(self.lib.beom_profile_stop(self.h, ms, nl, self._err, ERRLEN))
-        return list(ms)[:7], list(nl)[:7]
+        return list(ms)[:8], list(nl)[:8]
 
     def field_tensors(self, names=("hlay", "u", "v", "h_u", "h_v")):
         """Zero-copy torch views [nlay, layer stride] of the device-resident prognostic fields.  Handles on the
@@ -370,7 +370,7 @@ class Engine:
         self._check(self.lib.beom_profile_steps(self.h, tstp_first, nsteps, tres, float(p.dtd8),
                                                 float(p.dt_r), float(p.rsta), p.n_3d, ms, nl,
                                                 self._err, ERRLEN))
-        return list(ms)[:7], list(nl)[:7]
+        return list(ms)[:8], list(nl)[:8]
 
     @property
     def is_dense(self) -> bool:
@@ -471,7 +471,7 @@ class MultiEngine:
         ms = (C.c_double * 8)()
         nl = (C.c_int * 8)()
         self._check(self.lib.beom_multi_profile_stop(self.h, ms, nl, self._err, ERRLEN))
-        return list(ms)[:7], list(nl)[:7]
+        return list(ms)[:8], list(nl)[:8]
 
     def profile_steps(self, tstp_first: int, nsteps: int, tres: float = 0.0):
         self.profile_start()

@@ -69,6 +69,8 @@ struct beom_engine {
     bool lean_visc = true;             // zero viscosity (dvis = bvis = 0, v_cc = v_ll = +0): fused pair drops the viscous products
     bool visc_all_zero = true;         // no non-(+0) v_cc / v_ll has been uploaded
     bool lean_d2h = true;              // fused pair: d2hx, d2hy re-derived from hlay in k_uv_fused, not stored by k_mont_visc
+    bool fuse_muv = false;             // Montgomery + Leith folded into the momentum sweep (k_muv): measured SLOWER than the two
+                                       // fused sweeps (4.4 vs 3.1 ms at 4096^2 x 4: 229 VGPRs, two waves per SIMD), so opt-in
     char last_err[512] = {0};
 };
 
@@ -285,6 +287,7 @@ int beom_create(const beom_params *prm, int device, const int32_t *neig, const i
     d.keep_diag = 0; d.lean_d2h = 0; E->lean_d2h = true;
     E->fuse = getenv("BEOM_NO_FUSE") == nullptr;
     E->fuse_uv = getenv("BEOM_NO_FUSE") == nullptr && getenv("BEOM_NO_FUSE_UV") == nullptr;
+    E->fuse_muv = getenv("BEOM_MUV") != nullptr;
     E->wind = false;
     if (taus) for (size_t i = 0; i < 2 * n1h; ++i) if (std::fabs(taus[i]) > 1.e-7) { E->wind = true; break; }   // :1945
     E->bot = prm->bdrg > 1.e-7;                                                                                  // :1969
@@ -566,6 +569,25 @@ static void launch_uv_fused(beom_engine *E, bool first_x, bool prod, double gene
     }
     if (swap) uv_fused_swap(E, first_x);
 }
+// Montgomery + Leith + u + v as ONE sweep (k_muv) after the edge tiles' k_mont_visc; false if no instantiation
+// (two calls so that a split step can give each its own rows, as for the separate sweeps)
+static bool launch_muv_edges(beom_engine *E, bool leith) {
+    E->d.only_shallow = 1;
+    const bool ok = launch_mont_visc(E, true, leith, false);
+    E->d.only_shallow = 0;
+    return ok;
+}
+static bool launch_muv(beom_engine *E, bool first_x, bool leith, double gene, double ramp, double ctim, bool swap = true) {
+    DevView &d = E->d;
+    const dim3 g = muv_grid(d), b(UV_BLOCK);
+    const bool zv = d.zero_visc;
+#define MUV_GO(fx, le, z) hipLaunchKernelGGL((k_muv<fx, le, z>), g, b, 0, E->stream, d, gene, ramp, ctim)
+    if (first_x) { if (leith) MUV_GO(true, true, false); else if (zv) MUV_GO(true, false, true); else MUV_GO(true, false, false); }
+    else         { if (leith) MUV_GO(false, true, false); else if (zv) MUV_GO(false, false, true); else MUV_GO(false, false, false); }
+#undef MUV_GO
+    if (swap) uv_fused_swap(E, first_x);
+    return true;
+}
 static bool can_fuse(const beom_engine *E, int n_3d, bool first3) {
     // either every step refreshes the viscosity (dvis > 1e-3 and n_3d = 1, :2268) — Montgomery + Leith
     // in one sweep — or no step after the third ever does (dvis <= 1e-3, svis = 0): v_cc, v_ll stand
@@ -604,7 +626,7 @@ int beom_distribute_stress(beom_handle E) { NEED(E); launch_stress(E); return LA
 }  // extern "C"
 
 // Per-step scalars of integrate_time (private_mod.f95:1858-1901).
-struct StepScalars { double ctim, ramp, gene; bool first3, upst, stress, fused, fused_uv; int n_3d; };
+struct StepScalars { double ctim, ramp, gene; bool first3, upst, stress, fused, fused_uv, muv; int n_3d; };
 static StepScalars step_scalars(const beom_engine *E, int tstp, double tres, double dtd8, double dt_r,
                                 double rsta, int n_3d) {
     StepScalars s;
@@ -625,6 +647,10 @@ static StepScalars step_scalars(const beom_engine *E, int tstp, double tres, dou
     s.n_3d = n_3d;
     s.fused = can_fuse(E, n_3d, s.first3);
     s.fused_uv = E->dense && E->fuse_uv && !(E->P.svis > 0.0);
+    // one sweep for Montgomery, Leith, u and v: needs both fusions, the re-derived curvatures, and a viscosity that is
+    // either refreshed on every step or never again (no v_cc, v_ll to keep standing between refreshes)
+    s.muv = s.fused && s.fused_uv && E->fuse_muv && E->lean_d2h && !E->d.keep_diag && E->d.nlay <= 8 &&
+            (n_3d == 1 || !(E->P.dvis > 1.e-3)) && !E->obc;
     return s;
 }
 
@@ -635,8 +661,17 @@ static void one_step(beom_engine *E, int tstp, const StepScalars &s) {
     if (s.first3) launch_rebuild(E);                               // :2166-2177
     if (T) T->begin(0);
     launch_h(E, s.gene, s.ramp, s.ctim);                           // :2181,2259
-    if (T) { T->end(); T->begin(s.fused ? 5 : 1); }
     const bool leith = E->P.dvis > 1.e-3 && s.upst;
+    const bool u_first = tstp % 2 == 0;                            // :2193-2199,2276-2282
+    if (s.muv) {                                                   // :2187-2199, 2266-2282 in one sweep
+        if (T) { T->end(); T->begin(5); }
+        launch_muv_edges(E, leith);
+        if (T) { T->end(); T->begin(7); }
+        launch_muv(E, u_first, leith, s.gene, s.ramp, s.ctim);
+        if (T) T->end();
+        return;
+    }
+    if (T) { T->end(); T->begin(s.fused ? 5 : 1); }
     const bool prod = s.fused && launch_mont_visc(E, s.fused_uv, leith, leith && s.n_3d > 1);              // :2187-2188, 2266-2269 in one sweep
     if (!prod) launch_mont(E, 0);
     if (T) T->end();
@@ -645,7 +680,6 @@ static void one_step(beom_engine *E, int tstp, const StepScalars &s) {
         launch_visc(E, 0);
         if (T) T->end();
     }
-    const bool u_first = tstp % 2 == 0;                            // :2193-2199,2276-2282
     if (s.fused_uv) {
         if (T) T->begin(6);
         launch_uv_fused(E, u_first, prod, s.gene, s.ramp, s.ctim);
@@ -698,7 +732,7 @@ int beom_profile_stop(beom_handle E, double *ms, int *launches, char *errm, int 
     HIP_TRY(hipSetDevice(E->device));
     HIP_TRY(hipStreamSynchronize(E->stream));
     StepTimer &T = *E->timer;
-    for (int c = 0; c < 7; ++c) { ms[c] = 0.0; launches[c] = 0; }
+    for (int c = 0; c < 8; ++c) { ms[c] = 0.0; launches[c] = 0; }
     for (size_t k = 0; k < T.cls.size(); ++k) {
         float t = 0.f;
         (void)hipEventElapsedTime(&t, T.ev[2 * k], T.ev[2 * k + 1]);
@@ -754,13 +788,24 @@ int beom_step_phase(beom_handle E, int tstp, double tres, double dtd8, double dt
         set_rows(d, 1, south ? 9 : 1, north ? M - 8 : M);
         if (T) T->begin(0);
         launch_h(E, s.gene, s.ramp, s.ctim, false);
-        if (T) { T->end(); T->begin(s.fused ? 5 : 1); }
-        set_rows(d, 1, south ? 10 : 1, north ? M - 9 : M);
-        if (s.fused) launch_mont_visc(E, true, E->P.dvis > 1.e-3 && s.upst, E->P.dvis > 1.e-3 && s.upst && s.n_3d > 1); else launch_mont(E, 0);
-        if (T) { T->end(); T->begin(6); }
-        set_rows(d, 1, south ? 11 : 1, north ? M - 10 : M);
-        launch_uv_fused(E, u_first, s.fused, s.gene, s.ramp, s.ctim, false);
         if (T) T->end();
+        if (s.muv) {
+            if (T) T->begin(5);
+            set_rows(d, 1, south ? 10 : 1, north ? M - 9 : M);
+            launch_muv_edges(E, E->P.dvis > 1.e-3 && s.upst);
+            if (T) { T->end(); T->begin(7); }
+            set_rows(d, 1, south ? 11 : 1, north ? M - 10 : M);
+            launch_muv(E, u_first, E->P.dvis > 1.e-3 && s.upst, s.gene, s.ramp, s.ctim, false);
+            if (T) T->end();
+        } else {
+            if (T) T->begin(s.fused ? 5 : 1);
+            set_rows(d, 1, south ? 10 : 1, north ? M - 9 : M);
+            if (s.fused) launch_mont_visc(E, true, E->P.dvis > 1.e-3 && s.upst, E->P.dvis > 1.e-3 && s.upst && s.n_3d > 1); else launch_mont(E, 0);
+            if (T) { T->end(); T->begin(6); }
+            set_rows(d, 1, south ? 11 : 1, north ? M - 10 : M);
+            launch_uv_fused(E, u_first, s.fused, s.gene, s.ramp, s.ctim, false);
+            if (T) T->end();
+        }
     } else {
         // edge strips; a side without a neighbour has no strip (its rows were done in phase 1)
         auto strips = [&](int depth) {
@@ -771,13 +816,24 @@ int beom_step_phase(beom_handle E, int tstp, double tres, double dtd8, double dt
         strips(8);
         if (T) T->begin(0);
         launch_h(E, s.gene, s.ramp, s.ctim, true);
-        if (T) { T->end(); T->begin(s.fused ? 5 : 1); }
-        strips(9);
-        if (s.fused) launch_mont_visc(E, true, E->P.dvis > 1.e-3 && s.upst, E->P.dvis > 1.e-3 && s.upst && s.n_3d > 1); else launch_mont(E, 0);
-        if (T) { T->end(); T->begin(6); }
-        strips(10);
-        launch_uv_fused(E, u_first, s.fused, s.gene, s.ramp, s.ctim, true);
         if (T) T->end();
+        if (s.muv) {
+            if (T) T->begin(5);
+            strips(9);
+            launch_muv_edges(E, E->P.dvis > 1.e-3 && s.upst);
+            if (T) { T->end(); T->begin(7); }
+            strips(10);
+            launch_muv(E, u_first, E->P.dvis > 1.e-3 && s.upst, s.gene, s.ramp, s.ctim, true);
+            if (T) T->end();
+        } else {
+            if (T) T->begin(s.fused ? 5 : 1);
+            strips(9);
+            if (s.fused) launch_mont_visc(E, true, E->P.dvis > 1.e-3 && s.upst, E->P.dvis > 1.e-3 && s.upst && s.n_3d > 1); else launch_mont(E, 0);
+            if (T) { T->end(); T->begin(6); }
+            strips(10);
+            launch_uv_fused(E, u_first, s.fused, s.gene, s.ramp, s.ctim, true);
+            if (T) T->end();
+        }
     }
     set_rows(d, 1, 1, M);
     HIP_TRY(hipGetLastError());
@@ -902,6 +958,7 @@ int beom_set_option(beom_handle E, const char *name, int value) {
     if (!strcmp(name, "fuse")) { E->fuse = value != 0; E->fuse_uv = value != 0; }
     else if (!strcmp(name, "fuse_mont_visc")) E->fuse = value != 0;
     else if (!strcmp(name, "fuse_uv")) E->fuse_uv = value != 0;
+    else if (!strcmp(name, "fuse_muv")) E->fuse_muv = value != 0;
     else if (!strcmp(name, "keep_diag")) E->d.keep_diag = value != 0;
     else if (!strcmp(name, "lean_d2h")) E->lean_d2h = value != 0;
     else if (!strcmp(name, "lean_visc")) E->lean_visc = value != 0;

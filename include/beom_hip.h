@@ -175,6 +175,10 @@ int beom_unpack_rows(beom_handle h, int jlo, int nrows, const void *device_buffe
  *  "lean_d2h", "lean_visc" (default 1): the fused pair re-derives d2hx, d2hy in the momentum sweep,
  *      and drops the viscous products altogether when v_cc = v_ll = +0 and never refreshed.
  *  "fuse_uv" (default 1): update_u and update_v of a step run as ONE sweep.
+ *  "fuse_muv" (default 0 — measured slower than the two fused sweeps): with both fusions above, "lean_d2h", and a viscosity refreshed every step or never
+ *      after step 3: update_mont..., update_viscosity, update_u and update_v run as ONE sweep that derives
+ *      mont, pvor and the viscous products in LDS (never stored); only the frame's edge tiles still go
+ *      through the separate Montgomery sweep.
  *  "fuse": sets both.  0 = always five separate sweeps.
  * Returns -3 for an unknown name. */
 int beom_set_option(beom_handle h, const char *name, int value);
@@ -205,8 +209,9 @@ int beom_device_field(beom_handle h, const char *name, void **dptr,
 int beom_is_dense(beom_handle h);
 /* Per-kernel device time, measured with HIP events on the handle's stream around every
  * sweep launched by beom_step between start and stop (no host synchronisation in
- * between): ms[0..6] = update_h, update_mont, update_viscosity, update_u, update_v,
- * fused mont+viscosity, fused u+v (sums over launches), launches[0..6] = number of
+ * between): ms[0..7] = update_h, update_mont, update_viscosity, update_u, update_v,
+ * fused mont+viscosity, fused u+v, fused mont+viscosity+u+v (sums over launches; with the last one
+ * active, class 5 is the small launch for the frame's edge tiles), launches[0..7] = number of
  * launches in each class.  Both arrays need 8 entries. */
 int beom_profile_start(beom_handle h);
 int beom_profile_stop(beom_handle h, double *ms, int *launches, char *errm, int errm_len);

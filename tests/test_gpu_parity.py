@@ -34,7 +34,8 @@ MODES = {          # name: (dense_hint, fuse_mont_visc, fuse_uv, keep_diag)
     "dense_fused_keepdiag": (1, 1, 1, 1),
     "dense_fuse_mv_only": (1, 1, 0, 0),
     "dense_fuse_uv_only": (1, 0, 1, 0),
-    "dense_fused": (1, 1, 1, 0),       # the production default
+    "dense_fused_muv": (1, 1, 1, 0),   # opt-in: mont+visc+u+v in ONE sweep where it applies (k_muv)
+    "dense_fused": (1, 1, 1, 0),       # the production default: mont+visc and u+v as two fused sweeps
 }
 PROGNOSTIC = ("hlay", "u", "v", "h_u", "h_v", "rs_h", "dmdx", "dmdy", "tt3d", "tb3d", "tu3d")
 
@@ -45,6 +46,7 @@ def _engine(f, variant=0, mode="dense_fused", **kw):
     e.set_option("fuse_mont_visc", fmv)
     e.set_option("fuse_uv", fuv)
     e.set_option("keep_diag", keep)
+    e.set_option("fuse_muv", 1 if mode == "dense_fused_muv" else 0)
     return e
 
 
@@ -69,7 +71,7 @@ def test_step_matches_reference_golden(name, mode):
     g = Golden(name)
     e = _engine(_fields(g), variant=g.variant, mode=mode)
     exact = not g.uses_cos()
-    lossy = mode in ("dense_fused", "dense_fuse_mv_only") and _fusion_active(g, e)
+    lossy = mode in ("dense_fused", "dense_fused_muv", "dense_fuse_mv_only") and _fusion_active(g, e)
     t = 0
     for tgt in GOLDEN_STEPS:
         e.step(t + 1, tgt - t)
@@ -81,7 +83,7 @@ def test_step_matches_reference_golden(name, mode):
             for k in ("hlay", "u", "v", "h_u", "h_v"):
                 assert same_bits(st[k], g.step(tgt, k)), (name, tgt, k, "sign of zero")
         sc = e.download_scratch()
-        keys = SCRATCH if not lossy else (("mont", "pvor") if mode == "dense_fused" else ("mont", "pvor", "d2hx", "d2hy"))
+        keys = SCRATCH if not lossy else (("mont", "pvor") if mode in ("dense_fused", "dense_fused_muv") else ("mont", "pvor", "d2hx", "d2hy"))
         for k in keys:                                                        # reference scratch = last layer
             _check(sc[k][g.p.nlay - 1], g.step(tgt, k), exact, (name, tgt, k))
     e.close()
@@ -188,18 +190,23 @@ def test_lean_thickness_curvature_matches_oracle(case):
     else:
         p, files = I.case_sill_exchange3d(lm=330, mm=75, nlay=3, dt_s=0.01, npts=5, sill_halfwidth=20.0)
     f = read_input_data(p, files=files)
-    lean, full = capi.Engine(f), capi.Engine(f)
+    lean, full, muv = capi.Engine(f), capi.Engine(f), capi.Engine(f)
     full.set_option("lean_d2h", 0)
     full.set_option("lean_visc", 0)
+    muv.set_option("fuse_muv", 1)        # opt-in: Montgomery + Leith + u + v as ONE sweep in the deep tiles (k_muv)
     assert lean.is_dense
     o = oracle_lib.Oracle(f)
     n = 14
-    for x in (lean, full, o):
+    for x in (lean, full, muv, o):
         x.step(1, n)
-    sl, sf = lean.download(), full.download()
+    sl, sf, sm = lean.download(), full.download(), muv.download()
+    muv.close()
     for k in PROGNOSTIC:
         assert same(sl[k], o.state()[k]), (case, k, maxrel(sl[k], o.state()[k]))
         assert same(sf[k], sl[k]), (case, k)
+        assert same(sm[k], sl[k]), (case, k, "four-sweep launch")
+    for k in ("hlay", "u", "v", "h_u", "h_v"):
+        assert same_bits(sm[k], o.state()[k]), (case, k, "four-sweep launch, sign of zero")
     for k in ("hlay", "u", "v", "h_u", "h_v"):            # the sign of zero too
         assert same_bits(sl[k], o.state()[k]), (case, k, "sign of zero")
     cl, cf = lean.download_scratch(), full.download_scratch()
@@ -250,12 +257,12 @@ def test_dense_interior_waves_match_oracle_and_gather(case):
         x.step(1, 12)
     ref_sc = engines["gather"].download_scratch()
     for m, e in engines.items():
-        lossy = m in ("dense_fused", "dense_fuse_mv_only") and _fuses(p)
+        lossy = m in ("dense_fused", "dense_fused_muv", "dense_fuse_mv_only") and _fuses(p)
         st = e.download()
         for k in (PROGNOSTIC if lossy else STATE):
             assert same(st[k], o.state()[k]), (case, m, k, maxrel(st[k], o.state()[k]))
         sc = e.download_scratch()
-        keys = SCRATCH if not lossy else (("mont", "pvor") if m == "dense_fused" else ("mont", "pvor", "d2hx", "d2hy"))
+        keys = SCRATCH if not lossy else (() if m == "dense_fused_muv" else ("mont", "pvor") if m == "dense_fused" else ("mont", "pvor", "d2hx", "d2hy"))
         for k in keys:
             assert same(sc[k], ref_sc[k]), (case, m, k)
         e.close()
@@ -324,13 +331,19 @@ def test_profile_start_stop_counts_launches():
     e.profile_start()
     e.step(5, 6, sync=False)
     ms, nl = e.profile_stop()
-    assert nl == [6, 0, 0, 0, 0, 6, 6]    # fused: H, mont+visc, u+v
+    assert nl == [6, 0, 0, 0, 0, 6, 6, 0]    # fused pairs: H, mont+visc, u+v
+    e.set_option("fuse_muv", 1)
+    e.profile_start()
+    e.step(11, 6, sync=False)
+    ms, nl = e.profile_stop()
+    assert nl == [6, 0, 0, 0, 0, 6, 0, 6]    # H, mont+visc for the frame's edge tiles, mont+visc+u+v in one sweep
+    e.set_option("fuse_muv", 0)
     assert all(m > 0 for i, m in enumerate(ms) if nl[i])
     e.set_option("fuse", 0)
     e.profile_start()
-    e.step(11, 4, sync=False)
+    e.step(17, 4, sync=False)
     ms, nl = e.profile_stop()
-    assert nl == [4, 4, 4, 4, 4, 0, 0] and all(m > 0 for m in ms[:5])
+    assert nl == [4, 4, 4, 4, 4, 0, 0, 0] and all(m > 0 for m in ms[:5])
     e.close()
 
 
