@@ -59,7 +59,10 @@ __device__ __forceinline__ void body_update_h(const C &c, const DevView &d, doub
     const int ilay_lo = gridDim.y == 1 ? 1 : (int)blockIdx.y + 1;
     for (int ilay = ilay_hi; ilay >= ilay_lo; --ilay) {
         double hold = LL(d.hlay, ipnt, ilay);
-        const double hfor0 = FORCED ? FNUD_(ipnt, ilay, 1) : 0.0;        // fetched with the rest, used at the end
+        // Sponges cover a few rows or columns of a frame: where the cell's relaxation rate is zero the target
+        // thickness is not fetched at all (FORCE = 1, variant 0; see the epilogue) — a word per cell-layer saved
+        const bool lazy_hfor = FORCE == 1 && d.variant == 0;
+        const double hfor0 = (FORCED && !(lazy_hfor && ng == 0.0)) ? FNUD_(ipnt, ilay, 1) : 0.0;        // fetched with the rest, used at the end
         const double hu0 = LL(d.h_u, ipnt, ilay);
         double huE;
         if (C::kLanesAreRowNeighbours) {        // flux divergence in x: east value by wavefront shuffle
@@ -90,7 +93,12 @@ __device__ __forceinline__ void body_update_h(const C &c, const DevView &d, doub
                 const double vecl = (ilay == 1) ? 1.0 : 0.0;
                 hfor = hfor + ramp * TIDE_(1, ipnt, 1) * vecl * cos(TIDE_(2, ipnt, 1) - d.w_ti * ctim);
             }
-            if (d.variant == 0) {
+            if (lazy_hfor && ng == 0.0) {
+                // hfor*0 + (1-0)*hold = (+-0) + hold: hold itself unless hold is an exact zero — only those lanes
+                // (dry cells) fetch hfor for the sign of the result
+                hnew = hold;
+                if (hold == 0.0) hnew = FNUD_(ipnt, ilay, 1) * ng + (1.0 - ng) * hold;
+            } else if (d.variant == 0) {
                 hnew = hfor * ng + (1.0 - ng) * hold;
             } else {
                 const double hfor1 = 0.0, hfor2 = 800.0, hfor3 = 0.0;
@@ -649,8 +657,10 @@ __device__ __forceinline__ double uv_core(const C &c, const DevView &d, int ilay
     // pre (staged fused sweep): [0] this cell's velocity, [5..7] its history levels, loaded ahead of use
     double vold = pre ? pre[0] : LL(io.vel_in, ipnt, ilay);
     // nudging terms (wave-uniform switch): fetched up front, not next to their use further down
-    double f_fn = 0.0, f_ng = 0.0;
-    if (d.has_nudg) { f_fn = FNUD_(ipnt, ilay, IV); f_ng = NUDG_(ipnt, IV); }
+    // nudging rate of this point; the target velocity is fetched only where the rate is not zero (sponges cover a
+    // few rows or columns of a frame) or where the sign of an exact zero is at stake
+    double f_ng = 0.0;
+    if (d.has_nudg) f_ng = NUDG_(ipnt, IV);
     const double dmd4 = (sh.mont_b() - m_self) * i_dl * d.grav * mask;
     const double pva = sh.pvor_a();
     double rhsi = dmd4 * (1.0 - gene);
@@ -710,11 +720,11 @@ __device__ __forceinline__ double uv_core(const C &c, const DevView &d, int ilay
         else      rhsi = rhsi + (vc0 * dv0 - vcb * dvb) * i_dl + (vla * rva - vl0 * rv0) * i_dl;
     }
     vold = vold + rhsi * mask * d.dt;
-    // Without nudging the reference still evaluates vfor*0 + vold*(1-0); that differs from vold only
-    // in the sign of an exact zero, so those (rare) lanes alone go through the full expression.
-    if (d.has_nudg || vold == 0.0) {
+    // Rate zero (or no nudging at all): the reference still evaluates vfor*0 + vold*(1-0) = (+-0) + vold, i.e. vold
+    // unless vold is an exact zero, so only those (rare) lanes go through the full expression.
+    if (f_ng != 0.0 || vold == 0.0) {
         const double i__hh = 1.0 / (hcen + 1.0 - mask);
-        double vfor = d.has_nudg ? f_fn : FNUD_(ipnt, ilay, IV);
+        double vfor = FNUD_(ipnt, ilay, IV);
         if (d.has_stress) {
             const double ek = 0.5 * (T3_(d.tt3d, ipnt, IO, ilay) + T3_(d.tt3d, cb, IO, ilay))
                               * i_r1 * d.invf * i__hh * ramp;
@@ -724,8 +734,7 @@ __device__ __forceinline__ double uv_core(const C &c, const DevView &d, int ilay
         }
         if (d.has_tide) vfor = vfor + ramp * TIDE_(1, ipnt, IV) * cos(TIDE_(2, ipnt, IV) - d.w_ti * ctim);
         else vfor = vfor + 0.0;                                         // ramp*0*cos(0)
-        const double ng = d.has_nudg ? f_ng : 0.0;
-        vold = vfor * ng + vold * (1.0 - ng);
+        vold = vfor * f_ng + vold * (1.0 - f_ng);
     }
     const double hnew = 0.5 * (vold + fabs(vold)) * (hcen - 0.16667 * sh.template d2h_b<XDIR>())
                       + 0.5 * (vold - fabs(vold)) * (hcen - 0.16667 * sh.template d2h_s<XDIR>());   // rgld = 0 (:1491,1577)
