@@ -49,6 +49,7 @@ struct DevView {
     int keep_visc;                // fused sweep (Leith) also stores v_cc, v_ll: they stand for n_3d - 1 more steps
     int zero_visc;                // v_cc = v_ll = +0 everywhere and never refreshed: the viscous products are +-0
     int lean_d2h;                 // fused sweep stores d2hx, d2hy only where the fused u+v sweep reads them
+    int edge_global;              // k_uv_fused: edge workgroups read global memory throughout (A/B switch; default: staged by lookup)
     int only_shallow;             // k_mont_visc: only the tiles a frame-edge workgroup of k_muv reads (k_muv derives the rest itself)
     // biharmonic viscosity (svis > 0, :2508-2599): Laplacians and thickness-weighted fluxes
     double *delu, *delv, *uu4, *vv4; double svis;

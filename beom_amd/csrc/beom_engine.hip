@@ -288,6 +288,7 @@ int beom_create(const beom_params *prm, int device, const int32_t *neig, const i
     E->fuse = getenv("BEOM_NO_FUSE") == nullptr;
     E->fuse_uv = getenv("BEOM_NO_FUSE") == nullptr && getenv("BEOM_NO_FUSE_UV") == nullptr;
     E->fuse_muv = getenv("BEOM_MUV") != nullptr;
+    d.edge_global = getenv("BEOM_EDGE_GLOBAL") != nullptr;
     E->wind = false;
     if (taus) for (size_t i = 0; i < 2 * n1h; ++i) if (std::fabs(taus[i]) > 1.e-7) { E->wind = true; break; }   // :1945
     E->bot = prm->bdrg > 1.e-7;                                                                                  // :1969

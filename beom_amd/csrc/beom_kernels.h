@@ -1016,11 +1016,151 @@ __device__ __forceinline__ void body_uv_fused(const DevView &d, int x0, int y0, 
     }
 }
 
+// Edge workgroups of the production pair (wraps, sentinel, masks): the five shared fields of tile + ring are
+// staged in LDS BY LOOKUP — the entry at a geometric position is what a NEIGHBOUR lookup of that position
+// returns (periodic wraps applied, index 0 outside the frame) — so both updates, ring cells included, read
+// them there like the interior workgroups do; masks stay the predicates of CellDenseT<false>, and the thickness
+// curvatures come from the arrays k_mont_visc stores for these tiles (they carry the coast masks, :2393-2404).
+// (Frames a few tiles tall or wide — the soliton channel, a band of a multi-GPU run — are mostly edge tiles.)
+template <bool XDIR>
+struct ShLdsEdge {                                   // field order in the stage: 0 mont 1 pvor 2 pcd 3 qlr
+    const UVstage *s; const double (*h)[UV_SLDX];    // h = the hlay image
+    int r, c;                                        // staged position of the cell (UVstage coordinates)
+    const DevView &d; int ipnt, cb, ilay;            // for the curvature arrays
+    static constexpr int RB = XDIR ? 0 : -1, CB = XDIR ? -1 : 0;   // b neighbour: W | S
+    static constexpr int RA = XDIR ? 1 : 0, CA = XDIR ? 0 : 1;     // a neighbour: N | E
+    __device__ __forceinline__ double hlay_s() const { return h[r][c]; }
+    __device__ __forceinline__ double hlay_b() const { return h[r + RB][c + CB]; }
+    __device__ __forceinline__ double mont_s() const { return s[0][r][c]; }
+    __device__ __forceinline__ double mont_b() const { return s[0][r + RB][c + CB]; }
+    __device__ __forceinline__ double pvor_s() const { return s[1][r][c]; }
+    __device__ __forceinline__ double pvor_a() const { return s[1][r + RA][c + CA]; }
+    __device__ __forceinline__ double pcd_s() const { return s[2][r][c]; }
+    __device__ __forceinline__ double pcd_b() const { return s[2][r + RB][c + CB]; }
+    __device__ __forceinline__ double qlr_s() const { return s[3][r][c]; }
+    __device__ __forceinline__ double qlr_a() const { return s[3][r + RA][c + CA]; }
+    template <bool X> __device__ __forceinline__ double d2h_s() const { return LL(X ? d.d2hx : d.d2hy, ipnt, ilay); }
+    template <bool X> __device__ __forceinline__ double d2h_b() const { return LL(X ? d.d2hx : d.d2hy, cb, ilay); }
+};
+
+template <bool FIRST_X>
+__device__ __forceinline__ void body_uv_fused_edge(const DevView &d, int x0, int y0, int ilay, double gene, double ramp,
+                                                   double ctim, double (*s_h)[UV_LDX], UVstage *s_f, double (*s_hl)[UV_HLDX]) {
+    static_assert(sizeof(double) * UV_HROWS * UV_HLDX >= sizeof(UVstage), "the hlay image fits the widened hlay stage");
+    double (*s_hs)[UV_SLDX] = (double (*)[UV_SLDX])s_hl;
+    const int tid = threadIdx.x;
+    const int lx = tid & 63, wy = tid >> 6;
+    const int i = x0 + lx;
+    constexpr int ROFF = FIRST_X ? 1 : 0, COFF = FIRST_X ? 0 : 1;      // s_h coordinates as in body_uv_fused
+    constexpr int NST = UV_SROWS * UV_SLDX, NIT = (NST + UV_BLOCK - 1) / UV_BLOCK;
+    // ---- stage by lookup
+    {
+        const double *src[5] = {d.mont, d.pvor, d.pcd, d.qlr, d.hlay};
+        double fv[NIT][5];
+        int frr[NIT], fcc[NIT];
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int idx = tid + k * UV_BLOCK;
+            const int idc = idx < NST ? idx : tid;
+            frr[k] = idc / UV_SLDX; fcc[k] = idc - frr[k] * UV_SLDX;
+            int a = x0 - 1 + fcc[k], b = y0 - 1 + frr[k];
+            const int t = halo_target<false>(d, a, b) ? a + (b - 1) * d.P : 0;     // 0: the sentinel (zero in every one of these arrays)
+#pragma unroll
+            for (int f = 0; f < 5; ++f) fv[k][f] = LL(src[f], t, ilay);
+        }
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            if (tid + k * UV_BLOCK < NST) {
+#pragma unroll
+                for (int f = 0; f < 4; ++f) s_f[f][frr[k]][fcc[k]] = fv[k][f];
+                s_hs[frr[k]][fcc[k]] = fv[k][4];
+            }
+        }
+    }
+    CellDenseT<false> c[UV_Q];
+    bool ok[UV_Q], wr[UV_Q];
+#pragma unroll
+    for (int q = 0; q < UV_Q; ++q) {
+        const int j = y0 + wy + UV_WAVES * q;
+        ok[q] = (i <= d.L) && (j <= d.M);
+        wr[q] = ok[q] && row_selected(d, j);       // cells outside the strips are evaluated, not stored
+        c[q].set_cell(d, ok[q] ? i : 1, ok[q] ? j : 1);
+    }
+    __syncthreads();
+    // ---- first update: own cells, then the ring cell
+#pragma unroll
+    for (int q = 0; q < UV_Q; ++q) {
+        const int r = wy + UV_WAVES * q, j = y0 + r;
+        double hnew = 0.0;
+        if (ok[q]) {
+            const int cb = FIRST_X ? c[q].template nb<5>() : c[q].template nb<7>();
+            if ((d.xper && i == d.L) || (d.yper && !d.slab && j == d.M)) {
+                // orphan column / row: the image at its position holds the WRAPPED cell's values (it is a wrap target),
+                // so the cell's own update reads global memory; and what it stages is what a lookup of it returns
+                const int ca = FIRST_X ? c[q].template nb<3>() : c[q].template nb<1>();
+                const ShGlobal sh{d, c[q].ipnt, cb, ca, ilay};
+                (void)uv_first_eval<FIRST_X, true, true, false>(d, c[q], ilay, gene, ramp, ctim, sh, wr[q]);
+                hnew = uv_first_halo<FIRST_X, true>(d, i, j, ilay, gene, ramp, ctim);
+            } else {
+                const ShLdsEdge<FIRST_X> sh{s_f, s_hs, r + 1, lx + 1, d, c[q].ipnt, cb, ilay};
+                hnew = uv_first_eval<FIRST_X, true, true, false>(d, c[q], ilay, gene, ramp, ctim, sh, wr[q]);
+            }
+        }
+        s_h[r + ROFF][lx + COFF] = hnew;
+    }
+    {
+        int rr = -1, cc = -1;
+        if (tid <= UV_TX) { rr = FIRST_X ? 0 : UV_TY; cc = tid; }                              // the extra row
+        else if (tid <= UV_TX + UV_TY) { rr = (tid - UV_TX - 1) + ROFF; cc = FIRST_X ? UV_TX : 0; }   // the extra column
+        if (rr >= 0) {
+            const int ga = (FIRST_X ? x0 : x0 - 1) + cc, gb = (FIRST_X ? y0 - 1 : y0) + rr;    // geometric position
+            int a = ga, b = gb;
+            double val = 0.0;                                     // outside the frame: h_u(0) = h_v(0) = 0
+            if (halo_target<false>(d, a, b)) {
+                if (a != ga || b != gb) {
+                    // a ring position beyond the periodic seam: the image around it is not the neighbourhood of the
+                    // cell it stands for (the wraps act on every lookup anew) — the rare global path
+                    val = uv_first_halo<FIRST_X, true>(d, ga, gb, ilay, gene, ramp, ctim);
+                } else {
+                    CellDenseT<false> h;
+                    h.set_cell(d, a, b);
+                    const int cb = FIRST_X ? h.template nb<5>() : h.template nb<7>();
+                    const ShLdsEdge<FIRST_X> sh{s_f, s_hs, gb - (y0 - 1), ga - (x0 - 1), d, h.ipnt, cb, ilay};
+                    val = uv_first_eval<FIRST_X, true, false, false>(d, h, ilay, gene, ramp, ctim, sh);
+                }
+            }
+            s_h[rr][cc] = val;
+        }
+    }
+    __syncthreads();
+    // ---- second component, transport of the first from LDS
+    double *const *dm = FIRST_X ? d.dmy : d.dmx;
+    const UVio io{FIRST_X ? d.v : d.u, FIRST_X ? d.v_alt : d.u_alt, FIRST_X ? d.hv_alt : d.hu_alt,
+                  dm[0], dm[1], dm[2], dm[0]};
+#pragma unroll
+    for (int q = 0; q < UV_Q; ++q) {
+        if (!wr[q]) continue;
+        const int r = wy + UV_WAVES * q;
+        double q0, qb, qa, qd;
+        if (FIRST_X) { q0 = s_h[r + 1][lx]; qb = s_h[r][lx]; qa = s_h[r + 1][lx + 1]; qd = s_h[r][lx + 1]; }
+        else         { q0 = s_h[r][lx + 1]; qb = s_h[r][lx]; qa = s_h[r + 1][lx + 1]; qd = s_h[r + 1][lx]; }
+        const int cb = !FIRST_X ? c[q].template nb<5>() : c[q].template nb<7>();
+        if ((d.xper && i == d.L) || (d.yper && !d.slab && y0 + r == d.M)) {      // orphan column / row: see above
+            const int ca = !FIRST_X ? c[q].template nb<3>() : c[q].template nb<1>();
+            const ShGlobal sh{d, c[q].ipnt, cb, ca, ilay};
+            uv_core<!FIRST_X, true, true>(c[q], d, ilay, gene, ramp, ctim, 0, io, q0, qb, qa, qd, sh);
+        } else {
+            const ShLdsEdge<!FIRST_X> sh{s_f, s_hs, r + 1, lx + 1, d, c[q].ipnt, cb, ilay};
+            uv_core<!FIRST_X, true, true>(c[q], d, ilay, gene, ramp, ctim, 0, io, q0, qb, qa, qd, sh);
+        }
+    }
+}
+
 // ZV (with PROD): v_cc = v_ll = +0 everywhere — interior workgroups drop the viscous products
 template <bool FIRST_X, bool PROD, bool ZV = false>
 __global__ __launch_bounds__(UV_BLOCK) void k_uv_fused(DevView d, double gene, double ramp, double ctim) {
     __shared__ double s_h[UV_TY + 1][UV_LDX];
-    __shared__ UVstage s_f[PROD ? (ZV ? 2 : 4) : 1];
+    __shared__ UVstage s_f[PROD ? 4 : 1];                    // (ZV: the interior workgroups use two of them, the edge ones all four)
     __shared__ double s_hl[PROD ? UV_HROWS : 1][UV_HLDX];
     const TileMap tm(d, UV_TX, UV_TY);
     int ty, ch;
@@ -1031,6 +1171,7 @@ __global__ __launch_bounds__(UV_BLOCK) void k_uv_fused(DevView d, double gene, d
                           && y0 - 1 + d.joff >= 2 && y0 + UV_TY + d.joff <= d.Mg - 2;
     if (interior && PROD) body_uv_fused_staged<FIRST_X, ZV>(d, x0, y0, ilay, gene, ramp, ctim, s_h, s_f, s_hl);
     else if (interior) body_uv_fused<FIRST_X, PROD, true>(d, x0, y0, ilay, gene, ramp, ctim, s_h);
+    else if (PROD && !d.edge_global) body_uv_fused_edge<FIRST_X>(d, x0, y0, ilay, gene, ramp, ctim, s_h, s_f, s_hl);
     else body_uv_fused<FIRST_X, PROD, false>(d, x0, y0, ilay, gene, ramp, ctim, s_h);
 }
 static inline dim3 uv_fused_grid(const DevView &d) {
