@@ -71,8 +71,19 @@ struct beom_engine {
     bool lean_d2h = true;              // fused pair: d2hx, d2hy re-derived from hlay in k_uv_fused, not stored by k_mont_visc
     bool fuse_muv = false;             // Montgomery + Leith folded into the momentum sweep (k_muv): measured SLOWER than the two
                                        // fused sweeps (4.4 vs 3.1 ms at 4096^2 x 4: 229 VGPRs, two waves per SIMD), so opt-in
+    // Launch-bound frames (a few hundred thousand cells: a sweep takes a few microseconds): runs of time steps are
+    // replayed from HIP graphs.  A graph holds one full PERIOD of the pointer rotations (histories, ping-pong
+    // partners, u/v order), so replaying it leaves every pointer where the capture found it.
+    struct StepGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int period = 0, parity = 0; std::vector<void *> key; };
+    std::vector<StepGraph> graphs;
+    int use_graph = -1;                // option "graph": -1 = automatic (small frames), 0 = never, 1 = whenever the step allows
+    long long graph_steps = 0, eager_steps = 0;
     char last_err[512] = {0};
 };
+static void graphs_clear(beom_engine *E) {
+    for (auto &g : E->graphs) { if (g.exec) (void)hipGraphExecDestroy(g.exec); if (g.graph) (void)hipGraphDestroy(g.graph); }
+    E->graphs.clear();
+}
 
 namespace {
 
@@ -334,6 +345,7 @@ int beom_destroy(beom_handle E) {
     if (!E) return 0;
     (void)hipSetDevice(E->device);
     if (E->stream) (void)hipStreamSynchronize(E->stream);
+    graphs_clear(E);
     for (void *p : E->allocs) (void)hipFree(p);
     if (E->stage) (void)hipFree(E->stage);
     if (E->timer) { for (hipEvent_t ev : E->timer->ev) (void)hipEventDestroy(ev); delete E->timer; }
@@ -393,6 +405,7 @@ int beom_upload_state(beom_handle E, const double *hlay, const double *u, const 
                       const double *tb3d, const double *tu3d, char *errm, int errm_len) {
     if (!E) { set_err(errm, errm_len, "null handle"); return -1; }
     HIP_TRY(hipSetDevice(E->device));
+    graphs_clear(E);                   // (the zero-viscosity and stress switches below select launches)
     DevView &d = E->d;
     const size_t nl = (size_t)d.nlay, n = ((size_t)d.ndeg + 1) * nl;
     int rc;
@@ -705,6 +718,51 @@ static void one_step(beom_engine *E, int tstp, const StepScalars &s) {
     }
 }
 
+// ---- HIP graphs for launch-bound frames -------------------------------------------------------------
+static std::vector<void *> pointer_key(const beom_engine *E) {
+    const DevView &d = E->d;
+    return {d.hlay, d.u, d.v, d.h_u, d.h_v, d.u_alt, d.v_alt, d.hu_alt, d.hv_alt, d.rs[0], d.rs[1],
+            d.dmx[0], d.dmx[1], d.dmx[2], d.dmx[3], d.dmy[0], d.dmy[1], d.dmy[2], d.dmy[3]};
+}
+// a step whose launches do not depend on tstp except through its parity: steady forward-backward stepping
+static bool graph_step_ok(const beom_engine *E, int tstp, double tres, double dtd8, double dt_r, double rsta, int n_3d) {
+    if (E->use_graph == 0 || E->timer || tstp <= 3 || n_3d != 1 || E->d.has_tide || E->d.slab) return false;
+    if (E->use_graph < 0 && (E->d.ncell * E->d.nlay > 4000000ll || !E->dense)) return false;
+    const double ctim = tres + dtd8 * (double)tstp;
+    if (rsta < 0.5 && ctim < dt_r && E->d.has_stress) return false;      // the wind is still ramping up (:1898-1901)
+    return true;
+}
+// the graph that starts from the present pointer state at a step of this parity; captured on first use
+static beom_engine::StepGraph *graph_for(beom_engine *E, int tstp, double tres, double dtd8, double dt_r, double rsta, int n_3d) {
+    const std::vector<void *> key = pointer_key(E);
+    for (auto &g : E->graphs) if (g.parity == (tstp & 1) && g.key == key) return &g;
+    if (E->graphs.size() >= 8) graphs_clear(E);
+    beom_engine::StepGraph g;
+    g.parity = tstp & 1; g.key = key;
+    const DevView saved = E->d;          // the captured launches do not run: on any failure the rotations are taken back
+    if (hipStreamBeginCapture(E->stream, hipStreamCaptureModeRelaxed) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    int n = 0;
+    do {            // the launches of one period; the host-side rotations run as usual and come back to `key`
+        one_step(E, tstp + n, step_scalars(E, tstp + n, tres, dtd8, dt_r, rsta, n_3d));
+        ++n;
+    } while (n < 96 && !(n % 2 == 0 && pointer_key(E) == key));
+    const bool closed = pointer_key(E) == key && n % 2 == 0;
+    hipError_t e = hipStreamEndCapture(E->stream, &g.graph);
+    if (e != hipSuccess || !closed) {
+        (void)hipGetLastError();
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+        E->d = saved;
+        E->use_graph = 0;                        // no period within reach / capture refused: stay eager from now on
+        return nullptr;
+    }
+    if (hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0) != hipSuccess) {
+        (void)hipGetLastError(); (void)hipGraphDestroy(g.graph); E->d = saved; E->use_graph = 0; return nullptr;
+    }
+    g.period = n;
+    E->graphs.push_back(g);
+    return &E->graphs.back();
+}
+
 extern "C" {
 
 int beom_step(beom_handle E, int tstp_first, int nsteps, double tres, double dtd8, double dt_r,
@@ -713,8 +771,22 @@ int beom_step(beom_handle E, int tstp_first, int nsteps, double tres, double dtd
     if (tstp_first < 1 || nsteps < 0 || n_3d < 1) { set_err(errm, errm_len, "beom_step: bad arguments"); return -3; }
     if (E->P.flag_nudging && E->P.mcbc < 0.5 && !E->obc) { set_err(errm, errm_len, "beom_step: mcbc = 0 with nudging needs beom_set_open_boundaries (no_gradient_obc, private_mod.f95:2613-2679)"); return -6; }
     HIP_TRY(hipSetDevice(E->device));
-    for (int tstp = tstp_first; tstp < tstp_first + nsteps; ++tstp)
-        one_step(E, tstp, step_scalars(E, tstp, tres, dtd8, dt_r, rsta, n_3d));
+    const int end = tstp_first + nsteps;
+    int tstp = tstp_first;
+    while (tstp < end) {
+        // enough steps ahead to pay for a capture (a few ms), and every one of them replayable
+        if (end - tstp >= 48 && graph_step_ok(E, tstp, tres, dtd8, dt_r, rsta, n_3d) &&
+            graph_step_ok(E, end - 1, tres, dtd8, dt_r, rsta, n_3d)) {
+            beom_engine::StepGraph *g = graph_for(E, tstp, tres, dtd8, dt_r, rsta, n_3d);
+            if (g) {
+                while (end - tstp >= g->period) {
+                    HIP_TRY(hipGraphLaunch(g->exec, E->stream));
+                    tstp += g->period; E->graph_steps += g->period;
+                }
+            }
+        }
+        if (tstp < end) { one_step(E, tstp, step_scalars(E, tstp, tres, dtd8, dt_r, rsta, n_3d)); ++tstp; ++E->eager_steps; }
+    }
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -948,18 +1020,28 @@ int beom_set_open_boundaries(beom_handle E, int nseg, const int32_t *segm, char 
     HIP_TRY(hipMalloc((void **)&dev, (size_t)nseg * 18 * sizeof(int32_t)));
     E->allocs.push_back(dev);
     HIP_TRY(hipMemcpy(dev, sg.data(), (size_t)nseg * 18 * sizeof(int32_t), hipMemcpyHostToDevice));
+    graphs_clear(E);
     E->d.segm = dev;
     E->d.nseg = nseg;
     E->obc = E->P.flag_nudging && E->P.mcbc < 0.5;
     return 0;
 }
 
+int beom_graph_stats(beom_handle E, long long *graph_steps, long long *eager_steps) {
+    if (!E) return -1;
+    if (graph_steps) *graph_steps = E->graph_steps;
+    if (eager_steps) *eager_steps = E->eager_steps;
+    return 0;
+}
+
 int beom_set_option(beom_handle E, const char *name, int value) {
     if (!E || !name) return -1;
+    graphs_clear(E);                   // launches baked into a graph may no longer be the ones this option selects
     if (!strcmp(name, "fuse")) { E->fuse = value != 0; E->fuse_uv = value != 0; }
     else if (!strcmp(name, "fuse_mont_visc")) E->fuse = value != 0;
     else if (!strcmp(name, "fuse_uv")) E->fuse_uv = value != 0;
     else if (!strcmp(name, "fuse_muv")) E->fuse_muv = value != 0;
+    else if (!strcmp(name, "graph")) E->use_graph = value;
     else if (!strcmp(name, "keep_diag")) E->d.keep_diag = value != 0;
     else if (!strcmp(name, "lean_d2h")) E->lean_d2h = value != 0;
     else if (!strcmp(name, "lean_visc")) E->lean_visc = value != 0;

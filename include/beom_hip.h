@@ -180,8 +180,13 @@ int beom_unpack_rows(beom_handle h, int jlo, int nrows, const void *device_buffe
  *      mont, pvor and the viscous products in LDS (never stored); only the frame's edge tiles still go
  *      through the separate Montgomery sweep.
  *  "fuse": sets both.  0 = always five separate sweeps.
+ *  "graph" (default -1 = automatic: dense frames of at most 4 M cell-layers): steady forward-backward steps (after the
+ *      third, no tide, n_3d = 1, wind fully ramped up) are replayed from HIP graphs, each holding one full period of the
+ *      pointer rotations — such frames are bound by launch latency, not by HBM.  0 = never, 1 = any dense frame.
  * Returns -3 for an unknown name. */
 int beom_set_option(beom_handle h, const char *name, int value);
+/* how many time steps of this handle ran from HIP graphs / as individual launches */
+int beom_graph_stats(beom_handle h, long long *graph_steps, long long *eager_steps);
 
 /* Run all launches of this handle on the caller's HIP stream (e.g. the stream a
  * ghost-row exchange is enqueued on).  hip_stream may be NULL = the default stream;

@@ -154,6 +154,32 @@ def test_long_run_matches_oracle():
     e.close()
 
 
+@pytest.mark.parametrize("case", ["soliton_xper", "stommel_wind_drag", "jet_xyper_2l", "sill_ocrp_nudg_4l", "beach_ocrp_8l"])
+def test_graph_replay_matches_oracle_and_eager(case):
+    """Launch-bound frames: steady steps are replayed from HIP graphs, each holding one period of the pointer
+    rotations (option "graph", automatic for small dense frames).  300 steps in uneven calls — graph replays,
+    eager remainders, an upload in between — against the oracle and against the same engine with graphs off."""
+    from beom_amd.grid import read_input_data
+    p, files = _big_cases()[case]()
+    f = read_input_data(p, files=files)
+    e, plain, o = capi.Engine(f), capi.Engine(f), oracle_lib.Oracle(f)
+    plain.set_option("graph", 0)
+    t = 1
+    for n in (3, 100, 57, 140):
+        e.step(t, n); plain.step(t, n); o.step(t, n)
+        t += n
+        if n == 57:                                   # scatter the state again: cached graphs must not go stale
+            e.upload(**e.download())
+    gs = e.graph_stats()
+    assert gs["graph_steps"] >= 150 and gs["graph_steps"] + gs["eager_steps"] == 300, gs
+    assert plain.graph_stats()["graph_steps"] == 0
+    a, b = e.download(), plain.download()
+    for k in PROGNOSTIC:
+        assert same(a[k], b[k]), (case, k, "graph vs eager")
+        assert same(a[k], o.state()[k]), (case, k, "graph vs oracle")
+    e.close(); plain.close()
+
+
 def test_restart_split_equals_single_run():
     """download → new handle → upload → continue == uninterrupted run (state incl. histories)."""
     g = Golden("sill_2l_ocrp")
