@@ -76,7 +76,8 @@ struct beom_engine {
     // partners, u/v order), so replaying it leaves every pointer where the capture found it.
     struct StepGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int period = 0, parity = 0; std::vector<void *> key; };
     std::vector<StepGraph> graphs;
-    int use_graph = -1;                // option "graph": -1 = automatic (small frames), 0 = never, 1 = whenever the step allows
+    int use_graph = 0;                 // option "graph": 0 = never (default: measured no gain), 1 = whenever the step allows,
+                                       // -1 = automatic (dense frames of at most 4 M cell-layers)
     long long graph_steps = 0, eager_steps = 0;
     char last_err[512] = {0};
 };

@@ -180,9 +180,10 @@ int beom_unpack_rows(beom_handle h, int jlo, int nrows, const void *device_buffe
  *      mont, pvor and the viscous products in LDS (never stored); only the frame's edge tiles still go
  *      through the separate Montgomery sweep.
  *  "fuse": sets both.  0 = always five separate sweeps.
- *  "graph" (default -1 = automatic: dense frames of at most 4 M cell-layers): steady forward-backward steps (after the
- *      third, no tide, n_3d = 1, wind fully ramped up) are replayed from HIP graphs, each holding one full period of the
- *      pointer rotations — such frames are bound by launch latency, not by HBM.  0 = never, 1 = any dense frame.
+ *  "graph" (default 0): 1 = steady forward-backward steps (after the third, no tide, n_3d = 1, wind fully ramped up) are
+ *      replayed from HIP graphs, each holding one full period of the pointer rotations; -1 = only for dense frames of at
+ *      most 4 M cell-layers.  Measured on the soliton (2048x256) and Stommel (128x128) frames: no gain over individual
+ *      launches (the sweeps of such frames are bound by their own dependent memory round trips), hence off by default.
  * Returns -3 for an unknown name. */
 int beom_set_option(beom_handle h, const char *name, int value);
 /* how many time steps of this handle ran from HIP graphs / as individual launches */

@@ -156,14 +156,14 @@ def test_long_run_matches_oracle():
 
 @pytest.mark.parametrize("case", ["soliton_xper", "stommel_wind_drag", "jet_xyper_2l", "sill_ocrp_nudg_4l", "beach_ocrp_8l"])
 def test_graph_replay_matches_oracle_and_eager(case):
-    """Launch-bound frames: steady steps are replayed from HIP graphs, each holding one period of the pointer
-    rotations (option "graph", automatic for small dense frames).  300 steps in uneven calls — graph replays,
+    """Option "graph": steady steps are replayed from HIP graphs, each holding one period of the pointer
+    rotations (opt-in: it brought no gain on the launch-bound frames it was meant for).  300 steps in uneven calls — graph replays,
     eager remainders, an upload in between — against the oracle and against the same engine with graphs off."""
     from beom_amd.grid import read_input_data
     p, files = _big_cases()[case]()
     f = read_input_data(p, files=files)
     e, plain, o = capi.Engine(f), capi.Engine(f), oracle_lib.Oracle(f)
-    plain.set_option("graph", 0)
+    e.set_option("graph", 1)
     t = 1
     for n in (3, 100, 57, 140):
         e.step(t, n); plain.step(t, n); o.step(t, n)
