@@ -158,6 +158,12 @@ def main():
     if rank == 0 and a.gpus == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(a.cpu_sample)
 
+    # Libraries underneath (RCCL prints a version banner at communicator creation) write to fd 1: the ONE line this
+    # script owes its caller goes to the real stdout, everything else to stderr
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -333,6 +339,8 @@ def main():
     if halo:
         out["config"]["halo"] = halo
     out["cpu_baseline"] = cpu
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
     if rank == 0:
         print(json.dumps(out))
         sys.stdout.flush()

@@ -1,76 +1,39 @@
 #!/usr/bin/env python3
-"""How much host time does one overlapped slab step cost?  Two slabs of one frame in ONE
-process on one GPU (the loopback form of tests/test_gpu_parity.py), transfer = device copy.
-Prints: host enqueue time per rank-step (tiny grid: the GPU is never the limit), and for an
-N=8-sized slab pair (4096 x ~520 rows x 4) the wall time per step against the same two
-slabs stepped without any exchange."""
+"""How much HOST time does one band-step of the multi-GPU loop cost now that the loop runs inside the library
+(beom_multi_step; round 1 drove it from Python: ~100 us per rank-step)?
+
+Two bands of one frame in ONE process on one GPU (peer copies; the RCCL form adds one grouped send/recv per
+step).  (a) tiny frame: the GPU is never the limit, so wall time per band-step of an asynchronous call = host
+enqueue time (launches, events, the exchange); (b) an N=8-sized band pair (4096 x ~520 rows x 4): wall time per
+step against the single handle = what the exchange machinery costs on the device."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
-from beom_amd import capi, inputs as I, slab
+from beom_amd import capi, inputs as I
 from beom_amd.grid import read_input_data
 
-
-def make(lm, mm, nlay):
+for (lm, mm, nlay, n, bands) in ((256, 128, 4, 2000, (1, 2)), (4096, 1024, 4, 100, (1, 2, 4))):
     p, files = I.case_headline(lm, mm, nlay)
     f = read_input_data(p, files=files)
-    runs = []
-    for g in slab.decompose(p.mm, p.lm, 2):
-        e = capi.Engine(slab.slice_fields(f, g), slab_row0=g.row0, slab_mm=p.mm)
-        r = slab.SlabRunner(e, g, p.nlay, dist=None, overlap=False)
-        r.overlap = True
-        r.main, r.comm = torch.cuda.Stream(), torch.cuda.Stream()
-        r.main.wait_stream(torch.cuda.current_stream())
-        e.set_stream(r.main.cuda_stream)
-        runs.append(r)
-    return runs
+    for nb in bands:
+        for transport in (("peer", capi.XCHG_PEER),) + ((("rccl-self-ring", capi.XCHG_RCCL),) if False else ()):
+            m = capi.MultiEngine(f, devices=[0] * nb, transport=transport[1])
+            m.step(1, 10)
+            t0 = time.perf_counter()
+            m.step(11, n, sync=False)                 # returns when everything is enqueued
+            t1 = time.perf_counter()
+            m.sync()
+            t2 = time.perf_counter()
+            print("%dx%dx%d, %d band(s), %s: host enqueue %.1f us per band-step, wall %.3f ms per step, %s"
+                  % (lm, mm, nlay, nb, transport[0], (t1 - t0) / n / nb * 1e6, (t2 - t0) / n * 1e3, m.stats()), flush=True)
+            m.close()
 
-
-def loop(runs, t0, n, exchange=True):
-    a, b = runs
-
-    def xfer(dst, src_runner, src):
-        def go():
-            torch.cuda.current_stream().wait_event(src_runner._packed)
-            dst.copy_(src, non_blocking=True)
-        return go
-    for t in range(t0, t0 + n):
-        for r in runs:
-            with torch.cuda.stream(r.main):
-                if exchange and r._pending is not None and r.engine.step_phase(t, 1):
-                    r._exchange_end()
-                    r.engine.step_phase(t, 2)
-                else:
-                    r._exchange_end()
-                    r.engine.step(t, 1, sync=False)
-        if exchange:
-            for r in runs:
-                r._begin_pack()
-            a._begin_transfer(xfer(a.recv_n, b, b.send_s))
-            b._begin_transfer(xfer(b.recv_s, a, a.send_n))
-
-
-for (lm, mm, nlay, n) in ((256, 128, 4, 400), (4096, 1024, 4, 60)):
-    runs = make(lm, mm, nlay)
-    loop(runs, 1, 10); [r.finish() for r in runs]; torch.cuda.synchronize()
-    t1 = time.perf_counter(); loop(runs, 11, n); t2 = time.perf_counter()
-    [r.finish() for r in runs]; torch.cuda.synchronize(); t3 = time.perf_counter()
-    loop(runs, 11 + n, n, exchange=False); [r.finish() for r in runs]; torch.cuda.synchronize()
-    t4 = time.perf_counter(); loop(runs, 11 + 2 * n, n, exchange=False); [r.finish() for r in runs]
-    torch.cuda.synchronize(); t5 = time.perf_counter()
-    print("%dx%dx%d two slabs: host enqueue %.1f us per rank-step; wall %.3f ms per step pair with "
-          "exchange, %.3f ms without" % (lm, mm, nlay, (t2 - t1) / n / 2 * 1e6, (t3 - t1) / n * 1e3,
-                                         (t5 - t4) / n * 1e3), flush=True)
-    for r in runs:
-        r.engine.close()
-
-# ---- the single-process form (beom_multi_*): same frame, 1 handle against 2 and 4 bands on this GPU
-import time as _t
-p, files = I.case_headline(4096, 1024, 4)
+# the ring form over RCCL with one rank (the only RCCL form a one-GPU box can run): jet frame, one band
+p, files = I.case_unstable_jet(lm=256, mm=128, nlay=2, dt_s=1.0)
 f = read_input_data(p, files=files)
-for nb in (1, 2, 4):
-    m = capi.MultiEngine(f, devices=[0] * nb)
+for tr, name in ((capi.XCHG_PEER, "peer"), (capi.XCHG_RCCL, "RCCL")):
+    m = capi.MultiEngine(f, devices=[0], transport=tr, ring1=True)
     m.step(1, 10)
-    t0 = _t.perf_counter(); m.step(11, 60); t1 = _t.perf_counter()
-    print("beom_multi 4096x1024x4, %d band(s) on one GPU: %.3f ms per step, %s" % (nb, (t1 - t0) / 60 * 1e3, m.stats()), flush=True)
+    t0 = time.perf_counter(); m.step(11, 2000, sync=False); t1 = time.perf_counter(); m.sync(); t2 = time.perf_counter()
+    print("jet 256x128x2 as a ring of ONE band + companion frame, %s: host enqueue %.1f us per step, wall %.3f ms per step"
+          % (name, (t1 - t0) / 2000 * 1e6, (t2 - t0) / 2000 * 1e3), flush=True)
     m.close()
