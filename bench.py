@@ -261,11 +261,14 @@ def main():
         tp = time.perf_counter()
         eng.step(1, 10)
         per = max((time.perf_counter() - tp) / 10, 1e-5)
-        chunk = max(10, int(0.25 / per))
-        prewarm_steps = 10
-        while time.perf_counter() - tp < a.prewarm_s:
-            eng.step(prewarm_steps + 1, chunk)
-            prewarm_steps += chunk
+        if world > 1:                 # every rank must take the SAME number of steps (each step is an exchange)
+            tt = torch.tensor([per], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            per = float(tt.item())
+        more = max(0, min(int(a.prewarm_s / per) - 10, 20000))
+        if more:
+            eng.step(11, more)
+        prewarm_steps = 10 + more
         reset()
 
     # warm-up: steps 1..W (the first three are plain forward-backward, private_mod.f95:1859-1877)
