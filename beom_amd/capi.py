@@ -381,7 +381,13 @@ class Engine:
 
     @property
     def is_dense(self) -> bool:
+        """The tiled fast path is active (frames without land, or with land embedded in the rectangle)."""
         return bool(self.lib.beom_is_dense(self.h))
+
+    @property
+    def is_embedded(self) -> bool:
+        """A frame with land running on the rectangle (masks from arrays in the tiles that touch land)."""
+        return self.lib.beom_is_dense(self.h) == 2
 
     # per-sweep entry points (parity tests)
     def update_h(self, gene, ramp, ctim): self._check(self.lib.beom_update_h(self.h, gene, ramp, ctim))

@@ -27,6 +27,14 @@ struct DevView {
     // P = 0: packed layout (handles on the table path).  ncell = last cell index (P*M, or ndeg).
     int P;
     long long ncell;
+    // Frames WITH LAND on the same rectangle ("embedded", round 2): every (i, j) of the (lm+1) x (mm+1) frame has a slot;
+    // slots that are not packed cells of the caller's vector hold the sentinel's values and are never written, so a
+    // neighbour taken by offset reads there exactly what the reference reads at index 0.  Masks then come from the
+    // caller's arrays, and only tiles whose whole stencil is wet interior (reg4) take the mask-free paths.
+    int embedded;
+    const int32_t *pk_of;         // slot -> packed index (ipnt of the caller), 0 = not a packed cell; null unless embedded
+    const unsigned char *reg4;    // per 64 x 4 tile: 1 = every cell within 3 cells of it is wet interior with unit masks
+    int reg_nx;                   // tiles per row of reg4
     int joff, Mg, slab;           // j-slab: local row j is global row j + joff of Mg = mm_global+1 rows
     // rows a launch may WRITE: up to two strips [jlo, jhi] (local, inclusive); default one strip 1..M.
     // Used to split a step into an interior pass and an edge pass around the ghost-row exchange.
@@ -100,16 +108,29 @@ struct TileMap {
 __host__ __device__ __forceinline__ bool row_selected(const DevView &d, int j) {
     return (j >= d.jlo0 && j <= d.jhi0) || (d.nstrip > 1 && j >= d.jlo1 && j <= d.jhi1);
 }
+// embedded frames: is the 64 x ny tile at (x0, y0) (1-based, ny = 4 or 8, aligned) regular — no land, coast or mask
+// within 3 cells of it?  (frames without land: always)
+__device__ __forceinline__ bool tile_regular(const DevView &d, int x0, int y0, int ny) {
+    if (!d.embedded) return true;
+    const int tx = (x0 - 1) >> 6, t4 = (y0 - 1) >> 2;
+    if (tx < 0 || tx >= d.reg_nx || t4 < 0 || (t4 + (ny >> 2) - 1) * 4 >= d.M) return false;
+    bool r = d.reg4[(long long)t4 * d.reg_nx + tx] != 0;
+    if (ny > 4) r = r && d.reg4[(long long)(t4 + 1) * d.reg_nx + tx] != 0;
+    return r;
+}
+__device__ __forceinline__ bool slot_is_cell(const DevView &d, int ip) { return !d.embedded || d.pk_of[ip] != 0; }
 
 // launches over ALL cell slots 0..d.ncell (stress, output scans, ...): false for the padding slots of the dense layout
 __device__ __forceinline__ bool cell_slot(const DevView &d, long long ip) {
     if (ip > d.ncell) return false;
     if (d.P == 0 || ip == 0) return true;
+    if (d.embedded) return d.pk_of[ip] != 0;
     return (int)((ip - 1) % d.P) < d.L;
 }
 // 0-based packed index (the reference's ipnt - 1) of a real cell slot
 __device__ __forceinline__ long long packed_index0(const DevView &d, long long ip) {
     if (d.P == 0) return ip - 1;
+    if (d.embedded) return (long long)d.pk_of[ip] - 1;
     const long long r = (ip - 1) / d.P;
     return r * d.L + ((ip - 1) - r * d.P);
 }
@@ -208,6 +229,7 @@ struct CellDenseT {
     static constexpr bool kLanesAreRowNeighbours = INTERIOR;
     int i, j, ipnt, L, M, P, xper, yper;
     int jg, Mg, ywrap;            // global row / row count (masks); y wrap only when not a slab
+    const DevView *dv;            // embedded frames: masks from the caller's arrays
     static dim3 grid(const DevView &d, int nz) {
         return dim3(TileMap(d, BEOM_TILE_X, BEOM_TILE_Y).blocks(), (unsigned)nz, 1);
     }
@@ -221,22 +243,28 @@ struct CellDenseT {
         i = ch * BEOM_TILE_X + (wave % BEOM_TILE_WX) * 64 + ((int)threadIdx.x & 63) + 1;
         ipnt = i + (j - 1) * P;
         jg = j + d.joff; Mg = d.Mg; ywrap = d.yper && !d.slab;
-        return j <= M && i <= L && row_selected(d, j);
+        dv = &d;
+        if (!(j <= M && i <= L && row_selected(d, j))) return false;
+        return slot_is_cell(d, ipnt);             // (embedded: land slots keep the sentinel's values)
     }
     // context of an arbitrary LOCAL cell (a, b) of the same frame (used for halo cells)
     __device__ __forceinline__ void set_cell(const DevView &d, int a, int b) {
         L = d.L; M = d.M; P = d.P; xper = d.xper; yper = d.yper;
         i = a; j = b; ipnt = a + (b - 1) * P;
         jg = b + d.joff; Mg = d.Mg; ywrap = d.yper && !d.slab;
+        dv = &d;
     }
     // wave-uniform: do all 64 cells of this wave satisfy 2 <= i <= L-2, 2 <= j <= M-2 ?
     __device__ __forceinline__ bool wave_is_interior() const {
         const int i0 = __builtin_amdgcn_readfirstlane(i - ((int)threadIdx.x & 63));   // first column of the wave
-        return i0 >= 2 && i0 + 63 <= L - 2 && j >= 2 && j <= M - 2 && jg >= 2 && jg <= Mg - 2;
+        if (!(i0 >= 2 && i0 + 63 <= L - 2 && j >= 2 && j <= M - 2 && jg >= 2 && jg <= Mg - 2)) return false;
+        if (!dv->embedded) return true;
+        // (a wave = 64 cells of one row starting at a multiple of 64 + 1: inside one 64 x 4 tile of reg4)
+        return dv->reg4[(long long)((j - 1) >> 2) * dv->reg_nx + ((i0 - 1) >> 6)] != 0 && ((i0 - 1) & 63) == 0;
     }
     __device__ __forceinline__ CellDenseT<true> as_interior() const {
         CellDenseT<true> r; r.i = i; r.j = j; r.ipnt = ipnt; r.L = L; r.M = M; r.P = P; r.xper = xper; r.yper = yper;
-        r.jg = jg; r.Mg = Mg; r.ywrap = ywrap;
+        r.jg = jg; r.Mg = Mg; r.ywrap = ywrap; r.dv = dv;
         return r;
     }
     __device__ __forceinline__ int at(int a, int b) const {     // a, b: LOCAL target coordinates
@@ -252,15 +280,20 @@ struct CellDenseT {
     __device__ __forceinline__ static double f(bool c) { return c ? 1.0 : 0.0; }
     // masks are functions of the GLOBAL coordinates (i, jg) on the Mg-row frame
     __device__ __forceinline__ double mk_n_ij(int a, int bg) const { return f(a >= 1 && a <= L - 1 && bg >= 1 && bg <= Mg - 1); }
-    __device__ __forceinline__ double mk_n() const { return INTERIOR ? 1.0 : mk_n_ij(i, jg); }
-    __device__ __forceinline__ double mk_u() const { return INTERIOR ? 1.0 : f(jg <= Mg - 1 && i <= L - 1 && (i >= 2 || xper)); }
-    __device__ __forceinline__ double mk_v() const { return INTERIOR ? 1.0 : f(i <= L - 1 && jg <= Mg - 1 && (jg >= 2 || yper)); }
-    __device__ __forceinline__ double mkpe() const {
-        return INTERIOR ? 1.0 : f(i <= L - 1 && jg <= Mg - 1 && (i >= 2 || xper) && (jg >= 2 || yper));
+    __device__ __forceinline__ double mk_n() const { return INTERIOR ? 1.0 : (dv->embedded ? dv->mk_n[ipnt] : mk_n_ij(i, jg)); }
+    __device__ __forceinline__ double mk_u() const {
+        return INTERIOR ? 1.0 : (dv->embedded ? dv->mk_u[ipnt] : f(jg <= Mg - 1 && i <= L - 1 && (i >= 2 || xper)));
     }
-    __device__ __forceinline__ double mkpi() const { return 1.0; }
+    __device__ __forceinline__ double mk_v() const {
+        return INTERIOR ? 1.0 : (dv->embedded ? dv->mk_v[ipnt] : f(i <= L - 1 && jg <= Mg - 1 && (jg >= 2 || yper)));
+    }
+    __device__ __forceinline__ double mkpe() const {
+        return INTERIOR ? 1.0 : (dv->embedded ? dv->mkpe[ipnt] : f(i <= L - 1 && jg <= Mg - 1 && (i >= 2 || xper) && (jg >= 2 || yper)));
+    }
+    __device__ __forceinline__ double mkpi() const { return 1.0; }          // (only packed cells are evaluated)
     template <int K> __device__ __forceinline__ double mk_n_nb(int c) const {
         if (INTERIOR) return 1.0;
+        if (dv->embedded) return dv->mk_n[c];                    // (0 at the sentinel and at every land slot)
         if (c == 0) return 0.0;                                  // sentinel (also: outside a slab's window)
         int a = i + NbOff<K>::di, bg = jg + NbOff<K>::dj;
         if (xper) { if (a == 0) a = L - 1; else if (a == L) a = 1; }

@@ -54,6 +54,8 @@ struct beom_engine {
     DevView d{};
     bool dense = false;
     std::vector<void *> allocs;
+    int32_t *slot_of_dev = nullptr;    // embedded frames: packed index -> slot (device copy; null otherwise)
+    bool embedded = false;
     void *stage = nullptr;             // device image of ONE caller-layout slice [0:ndeg] (<= 32 B per cell) for uploads / downloads
     size_t stage_bytes = 0;
     // geometry of the launches
@@ -109,8 +111,13 @@ int slice_to_device(beom_engine *E, T *dev, const T *host, int inner, int K, int
     if (n * sizeof(T) > E->stage_bytes) { set_err(errm, errm_len, "internal: staging buffer too small"); return -11; }
     if (host) HIP_TRY(hipMemcpyAsync(E->stage, host, n * sizeof(T), hipMemcpyHostToDevice, E->stream));   // nullptr: the image is there already
     const long long work = ((long long)d.ndeg + 1) * inner;
+    if (E->embedded) {                 // land slots: the sentinel's value of this slice
+        const long long all = (d.ncell + 1) * inner;
+        hipLaunchKernelGGL((k_fill_sentinel<T>), dim3((unsigned)((all + BEOM_BLOCK - 1) / BEOM_BLOCK)), dim3(BEOM_BLOCK), 0, E->stream,
+                           dev, (const T *)E->stage, d.ncell + 1, inner, K, m);
+    }
     hipLaunchKernelGGL((k_repack<T, true, REMAP>), dim3((unsigned)((work + BEOM_BLOCK - 1) / BEOM_BLOCK)), dim3(BEOM_BLOCK), 0, E->stream,
-                       dev, (T *)E->stage, (long long)d.ndeg, d.L, d.P ? d.P : d.L, inner, K, m);
+                       dev, (T *)E->stage, (long long)d.ndeg, d.L, d.P ? d.P : d.L, inner, K, m, (const int32_t *)E->slot_of_dev);
     return 0;
 }
 template <class T>
@@ -127,7 +134,8 @@ void slice_gather(beom_engine *E, const T *dev, int inner, int K, int m) {      
     const DevView &d = E->d;
     const long long work = ((long long)d.ndeg + 1) * inner;
     hipLaunchKernelGGL((k_repack<T, false, false>), dim3((unsigned)((work + BEOM_BLOCK - 1) / BEOM_BLOCK)), dim3(BEOM_BLOCK), 0, E->stream,
-                       const_cast<T *>(dev), (T *)E->stage, (long long)d.ndeg, d.L, d.P ? d.P : d.L, inner, K, m);
+                       const_cast<T *>(dev), (T *)E->stage, (long long)d.ndeg, d.L, d.P ? d.P : d.L, inner, K, m,
+                       (const int32_t *)E->slot_of_dev);
 }
 
 // a static array [outer][0:ndeg][inner] of the caller -> a new device array; src == nullptr: zeros
@@ -235,10 +243,72 @@ int beom_create(const beom_params *prm, int device, const int32_t *neig, const i
                 }
             }
     }
+    // Frames with land: the same rectangle, every packed cell in the slot of its (i, j) (subc), if the
+    // caller's connectivity is what offsets on the rectangle give — wraps as for a dense frame, and wherever the table says
+    // 0 the offset lands outside the rectangle or on a slot that is no packed cell (it then holds the sentinel's values).
+    std::vector<int32_t> slot_of, pk_of;
+    std::vector<unsigned char> reg4;
+    if (!E->dense && prm->dense_hint && !d.slab && prm->svis == 0.0 && getenv("BEOM_NO_EMBED") == nullptr &&
+        !(prm->flag_nudging && prm->mcbc < 0.5) &&          // (no_gradient_obc works on the caller's segment table: table path)
+        (long long)d.L * d.M < 2000000000ll && (long long)prm->ndeg * 10 >= (long long)d.L * d.M * 3) {     // (at least 30 % of the rectangle in use)
+        const int L = d.L, M = d.M, P = (L + 15) / 16 * 16;
+        slot_of.assign(n1h, 0); pk_of.assign((size_t)P * M + 1, 0);
+        bool ok = true;
+        for (size_t p = 1; p < n1h && ok; ++p) {
+            const int i = subc[p], j = subc[p + n1h];
+            if (i < 1 || i > L || j < 1 || j > M) { ok = false; break; }
+            const int32_t sl = (int32_t)(i + (long long)(j - 1) * P);
+            if (pk_of[sl]) ok = false;
+            slot_of[p] = sl; pk_of[sl] = (int32_t)p;
+        }
+        for (int xp = 0; xp < 2 && ok && !E->embedded; ++xp)
+            for (int yp = 0; yp < 2 && !E->embedded; ++yp) {
+                const beom_dense::HostNb nb{L, M, xp, yp};
+                bool match = true;
+                for (size_t p = 1; p < n1h && match; ++p) {
+                    const int i = subc[p], j = subc[p + n1h];
+                    for (int k = 0; k < 8 && match; ++k) {
+                        const int q = nb.at(i + beom_dense::kDi[k], j + beom_dense::kDj[k]);      // packed-pitch index on the L x M rectangle, or 0
+                        const int32_t want = neig[k + 8 * p];
+                        const int32_t got = q ? pk_of[(size_t)((q - 1) % L + 1) + (size_t)((q - 1) / L) * P] : 0;
+                        match = want == got;
+                    }
+                }
+                if (match) { E->embedded = true; d.xper = xp; d.yper = yp; }
+            }
+        if (E->embedded) {
+            // 64 x 4 tiles whose every cell, and every cell within 3 of it, is wet interior with unit masks
+            const int ntx = (L + 63) / 64, nty = (M + 3) / 4;
+            std::vector<unsigned char> good((size_t)(L + 2) * (M + 2), 0);       // (i, j) in 0..L+1 x 0..M+1
+            for (size_t p = 1; p < n1h; ++p)
+                if (mk_n[p] == 1.0 && mk_u[p] == 1.0 && mk_v[p] == 1.0 && mkpe[p] == 1.0 && mkpi[p] == 1.0)
+                    good[(size_t)subc[p] + (size_t)subc[p + n1h] * (L + 2)] = 1;
+            // 2-D prefix sums of "not good" -> any bad cell in a window
+            std::vector<int32_t> bad((size_t)(L + 3) * (M + 3), 0);
+            for (int j = 0; j <= M + 1; ++j)
+                for (int i = 0; i <= L + 1; ++i)
+                    bad[(size_t)(i + 1) + (size_t)(j + 1) * (L + 3)] = (good[(size_t)i + (size_t)j * (L + 2)] ? 0 : 1)
+                        + bad[(size_t)i + (size_t)(j + 1) * (L + 3)] + bad[(size_t)(i + 1) + (size_t)j * (L + 3)] - bad[(size_t)i + (size_t)j * (L + 3)];
+            auto any_bad = [&](int i0, int i1, int j0, int j1) {          // inclusive window, clipped to 0..L+1 x 0..M+1 (the margin is bad)
+                if (i0 < 0 || j0 < 0 || i1 > L + 1 || j1 > M + 1) return true;
+                return bad[(size_t)(i1 + 1) + (size_t)(j1 + 1) * (L + 3)] - bad[(size_t)i0 + (size_t)(j1 + 1) * (L + 3)]
+                       - bad[(size_t)(i1 + 1) + (size_t)j0 * (L + 3)] + bad[(size_t)i0 + (size_t)j0 * (L + 3)] != 0;
+            };
+            reg4.assign((size_t)ntx * nty, 0);
+            for (int ty = 0; ty < nty; ++ty)
+                for (int tx = 0; tx < ntx; ++tx) {
+                    const int x0 = tx * 64 + 1, y0 = ty * 4 + 1;
+                    reg4[(size_t)ty * ntx + tx] = any_bad(x0 - 3, x0 + 63 + 3, y0 - 3, y0 + 3 + 3) ? 0 : 1;
+                }
+            d.reg_nx = ntx;
+            E->dense = true;              // the dense kernels, with masks from arrays where a tile is not regular
+        }
+    }
+    d.embedded = E->embedded ? 1 : 0;
     // device layout: padded row pitch for dense frames (DevView::P), the caller's packed layout otherwise
     d.P = 0; d.ncell = prm->ndeg;
     if (E->dense) {
-        d.P = getenv("BEOM_NO_PITCH") ? d.L : (d.L + 15) / 16 * 16;      // (BEOM_NO_PITCH: the packed pitch, for A/B measurements)
+        d.P = (getenv("BEOM_NO_PITCH") && !E->embedded) ? d.L : (d.L + 15) / 16 * 16;      // (BEOM_NO_PITCH: the packed pitch, for A/B measurements)
         d.ncell = (long long)d.P * d.M;
         d.n1 = (d.ncell + 1 + 15) / 16 * 16;
     }
@@ -246,6 +316,20 @@ int beom_create(const beom_params *prm, int device, const int32_t *neig, const i
     int rc = 0;
     E->stage_bytes = n1h * 32;                        // the widest slice: neig (8 x int32), a history (3 doubles)
     HIP_TRY_E(hipMalloc(&E->stage, E->stage_bytes));
+    if (E->embedded) {
+        int32_t *q = nullptr;
+        if ((rc = dev_alloc(E, &q, slot_of.size(), errm, errm_len, false))) { beom_destroy(E); return rc; }
+        HIP_TRY_E(hipMemcpyAsync(q, slot_of.data(), slot_of.size() * sizeof(int32_t), hipMemcpyHostToDevice, E->stream));
+        E->slot_of_dev = q;
+        if ((rc = dev_alloc(E, &q, (size_t)d.n1, errm, errm_len, true))) { beom_destroy(E); return rc; }
+        HIP_TRY_E(hipMemcpyAsync(q, pk_of.data(), pk_of.size() * sizeof(int32_t), hipMemcpyHostToDevice, E->stream));
+        d.pk_of = q;
+        unsigned char *r = nullptr;
+        if ((rc = dev_alloc(E, &r, reg4.size(), errm, errm_len, false))) { beom_destroy(E); return rc; }
+        HIP_TRY_E(hipMemcpyAsync(r, reg4.data(), reg4.size(), hipMemcpyHostToDevice, E->stream));
+        d.reg4 = r;
+        HIP_TRY_E(hipStreamSynchronize(E->stream));
+    }
 #define UP(name, src, outer, inner) if ((rc = dev_upload(E, &d.name, src, (size_t)(outer), (inner), errm, errm_len))) { beom_destroy(E); return rc; }
     if ((rc = dev_upload<int32_t, true>(E, &d.neig, neig, 1, 8, errm, errm_len))) { beom_destroy(E); return rc; }
     UP(subc, subc, 2, 1)
@@ -1011,6 +1095,7 @@ int beom_set_open_boundaries(beom_handle E, int nseg, const int32_t *segm, char 
     }
     // columns 1, 7, 10, 13, 16 are cell indices: to the device pitch
     std::vector<int32_t> sg(segm, segm + (size_t)nseg * 18);
+    if (E->embedded) { set_err(errm, errm_len, "beom_set_open_boundaries: internal: embedded frames keep the table path"); return -6; }
     if (E->d.P)
         for (int col : {1, 7, 10, 13, 16})
             for (int is = 0; is < nseg; ++is) {
@@ -1057,7 +1142,7 @@ int beom_set_stream(beom_handle E, void *hip_stream, int use_own) {
     return 0;
 }
 
-int beom_is_dense(beom_handle E) { return (E && E->dense) ? 1 : 0; }
+int beom_is_dense(beom_handle E) { return (E && E->dense) ? (E->embedded ? 2 : 1) : 0; }
 
 int beom_device_field(beom_handle E, const char *name, void **dptr, int64_t *stride_layer,
                       int64_t *stride_row, int64_t *row0_offset) {

@@ -285,12 +285,12 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_update_mont_all(DevView d) {
 #define UV_BLOCK (64 * UV_WAVES)
 #define UV_TY (UV_WAVES * UV_Q)
 // tile (x0, y0) and everything its fused evaluation reads (3 cells around it) inside the wet interior
-__host__ __device__ __forceinline__ bool muv_tile_interior(const DevView &d, int x0, int y0) {
+__device__ __forceinline__ bool muv_tile_interior(const DevView &d, int x0, int y0) {
     return x0 - 2 >= 2 && x0 + UV_TX + 1 <= d.L - 2 && y0 - 2 >= 2 && y0 + UV_TY + 1 <= d.M - 2
-           && y0 - 2 + d.joff >= 2 && y0 + UV_TY + 1 + d.joff <= d.Mg - 2;
+           && y0 - 2 + d.joff >= 2 && y0 + UV_TY + 1 + d.joff <= d.Mg - 2 && !d.embedded;      // (frames with land: the two fused sweeps)
 }
 // every tile around (and including) this one takes the fused path: nobody reads mont, pvor, pcd, qlr, d2h of it from memory
-__host__ __device__ __forceinline__ bool muv_tile_deep(const DevView &d, int x0, int y0) {
+__device__ __forceinline__ bool muv_tile_deep(const DevView &d, int x0, int y0) {
     return muv_tile_interior(d, x0 - UV_TX, y0 - UV_TY) && muv_tile_interior(d, x0 + UV_TX, y0 + UV_TY);
 }
 
@@ -348,6 +348,7 @@ __device__ __forceinline__ void body_mont_visc(const DevView &d, int x0, int y0,
     for (int q = 0; q < MV_Q; ++q) {
         const int j = y0 + wy + 4 * q;
         ok[q] = (i <= d.L) && (j <= d.M);
+        if (!INT && ok[q] && !slot_is_cell(d, i + (j - 1) * d.P)) ok[q] = false;     // embedded: a land slot is the sentinel
         wr[q] = ok[q] && row_selected(d, j);           // cells outside the strips are staged, not stored
         c[q].set_cell(d, ok[q] ? i : 1, ok[q] ? j : 1);
         n1[q] = c[q].template nb<1>(); n3[q] = c[q].template nb<3>(); n5[q] = c[q].template nb<5>();
@@ -362,7 +363,7 @@ __device__ __forceinline__ void body_mont_visc(const DevView &d, int x0, int y0,
             if (!ok[q]) widx[q] = 0;                   // beyond the frame: lookups give the sentinel
             else if ((d.xper && i == d.L) || (d.yper && !d.slab && j == d.M)) {
                 int a = i, b = j;
-                widx[q] = halo_target<INT>(d, a, b) ? a + (b - 1) * d.P : 0;
+                widx[q] = (halo_target<INT>(d, a, b) && slot_is_cell(d, a + (b - 1) * d.P)) ? a + (b - 1) * d.P : 0;
             }
         }
     }
@@ -377,7 +378,7 @@ __device__ __forceinline__ void body_mont_visc(const DevView &d, int x0, int y0,
     hcell.set_cell(d, 1, 1);
     if (hr >= 0) {
         int a = x0 - 1 + hc, b = y0 - 1 + hr;
-        if (halo_target<INT>(d, a, b)) { hcell.set_cell(d, a, b); hidx = hcell.ipnt; }
+        if (halo_target<INT>(d, a, b) && (INT || slot_is_cell(d, a + (b - 1) * d.P))) { hcell.set_cell(d, a, b); hidx = hcell.ipnt; }
     }
 
 #pragma unroll
@@ -518,12 +519,15 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_mont_visc(DevView d) {
     const int x0 = ch * MV_TX + 1, y0 = ty * MV_TY + 1;
     // block-uniform: tile and its ring lie in 2..L-2 x 2..M-2 (global rows too) -> no wraps, masks = 1
     const bool interior = x0 - 1 >= 2 && x0 + MV_TX <= d.L - 2 && y0 - 1 >= 2 && y0 + MV_TY <= d.M - 2
-                          && y0 - 1 + d.joff >= 2 && y0 + MV_TY + d.joff <= d.Mg - 2;
+                          && y0 - 1 + d.joff >= 2 && y0 + MV_TY + d.joff <= d.Mg - 2 && tile_regular(d, x0, y0, MV_TY);
     // d.lean_d2h (the fused u+v sweep follows): its interior workgroups re-derive d2hx, d2hy from
     // hlay; only tiles that touch a non-interior tile of that sweep (same tiling) still store them
     const int uy0 = ((y0 - 1) / UV_TY) * UV_TY + 1;          // first row of the k_uv_fused tile this tile lies in
-    const bool deep = x0 - 1 - UV_TX >= 2 && x0 + 2 * UV_TX <= d.L - 2 && uy0 - 1 - UV_TY >= 2 && uy0 + 2 * UV_TY <= d.M - 2
-                      && uy0 - 1 - UV_TY + d.joff >= 2 && uy0 + 2 * UV_TY + d.joff <= d.Mg - 2;
+    bool deep = x0 - 1 - UV_TX >= 2 && x0 + 2 * UV_TX <= d.L - 2 && uy0 - 1 - UV_TY >= 2 && uy0 + 2 * UV_TY <= d.M - 2
+                && uy0 - 1 - UV_TY + d.joff >= 2 && uy0 + 2 * UV_TY + d.joff <= d.Mg - 2;
+    if (deep && d.embedded)           // all nine k_uv_fused tiles around this one take the staged interior path
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) deep = deep && tile_regular(d, x0 + dx * UV_TX, uy0 + dy * UV_TY, UV_TY);
     if (d.only_shallow && muv_tile_deep(d, x0, uy0)) return;  // the fused Montgomery + momentum sweep follows: nobody reads this tile's results
     const bool wr_d2h = d.only_shallow || !(d.lean_d2h && deep);
     const bool wr_prod = d.only_shallow || !(d.zero_visc && deep);   // zero viscosity: interior workgroups of k_uv_fused skip the term
@@ -816,6 +820,7 @@ __device__ __forceinline__ double uv_first_halo(const DevView &d, int a, int b, 
     if (d.xper) { if (a == 0) a = d.L - 1; else if (a == d.L) a = 1; }
     if (d.yper && !d.slab) { if (b == 0) b = d.M - 1; else if (b == d.M) b = 1; }
     if (a < 1 || a > d.L || b < 1 || b > d.M) return 0.0;          // sentinel: h_u(0) = h_v(0) = 0
+    if (!slot_is_cell(d, a + (b - 1) * d.P)) return 0.0;           // embedded: a land slot reads as the sentinel
     CellDenseT<false> h;
     h.set_cell(d, a, b);
     const int cb = FIRST_X ? h.template nb<5>() : h.template nb<7>();
@@ -963,6 +968,7 @@ __device__ __forceinline__ void body_uv_fused(const DevView &d, int x0, int y0, 
     for (int q = 0; q < UV_Q; ++q) {
         const int r = wy + UV_WAVES * q, j = y0 + r;
         ok[q] = (i <= d.L) && (j <= d.M);
+        if (!INT && ok[q] && !slot_is_cell(d, i + (j - 1) * d.P)) ok[q] = false;     // embedded: land slots are never evaluated
         wr[q] = ok[q] && row_selected(d, j);       // cells outside the strips are evaluated, not stored
         c[q].set_cell(d, ok[q] ? i : 1, ok[q] ? j : 1);
         double hnew = 0.0;
@@ -1083,6 +1089,7 @@ __device__ __forceinline__ void body_uv_fused_edge(const DevView &d, int x0, int
     for (int q = 0; q < UV_Q; ++q) {
         const int j = y0 + wy + UV_WAVES * q;
         ok[q] = (i <= d.L) && (j <= d.M);
+        if (ok[q] && !slot_is_cell(d, i + (j - 1) * d.P)) ok[q] = false;     // embedded: land slots are never evaluated
         wr[q] = ok[q] && row_selected(d, j);       // cells outside the strips are evaluated, not stored
         c[q].set_cell(d, ok[q] ? i : 1, ok[q] ? j : 1);
     }
@@ -1116,7 +1123,7 @@ __device__ __forceinline__ void body_uv_fused_edge(const DevView &d, int x0, int
             const int ga = (FIRST_X ? x0 : x0 - 1) + cc, gb = (FIRST_X ? y0 - 1 : y0) + rr;    // geometric position
             int a = ga, b = gb;
             double val = 0.0;                                     // outside the frame: h_u(0) = h_v(0) = 0
-            if (halo_target<false>(d, a, b)) {
+            if (halo_target<false>(d, a, b) && slot_is_cell(d, a + (b - 1) * d.P)) {
                 if (a != ga || b != gb) {
                     // a ring position beyond the periodic seam: the image around it is not the neighbourhood of the
                     // cell it stands for (the wraps act on every lookup anew) — the rare global path
@@ -1168,7 +1175,7 @@ __global__ __launch_bounds__(UV_BLOCK) void k_uv_fused(DevView d, double gene, d
     const int x0 = ch * UV_TX + 1, y0 = ty * UV_TY + 1;
     const int ilay = blockIdx.y + 1;
     const bool interior = x0 - 1 >= 2 && x0 + UV_TX <= d.L - 2 && y0 - 1 >= 2 && y0 + UV_TY <= d.M - 2
-                          && y0 - 1 + d.joff >= 2 && y0 + UV_TY + d.joff <= d.Mg - 2;
+                          && y0 - 1 + d.joff >= 2 && y0 + UV_TY + d.joff <= d.Mg - 2 && tile_regular(d, x0, y0, UV_TY);
     if (interior && PROD) body_uv_fused_staged<FIRST_X, ZV>(d, x0, y0, ilay, gene, ramp, ctim, s_h, s_f, s_hl);
     else if (interior) body_uv_fused<FIRST_X, PROD, true>(d, x0, y0, ilay, gene, ramp, ctim, s_h);
     else if (PROD && !d.edge_global) body_uv_fused_edge<FIRST_X>(d, x0, y0, ilay, gene, ramp, ctim, s_h, s_f, s_hl);
@@ -1392,7 +1399,7 @@ __global__ __launch_bounds__(UV_BLOCK, 2) void k_muv(DevView d, double gene, dou
     }
     // the frame's edge tiles: the momentum sweep from the arrays k_mont_visc stored for them, layer by layer
     const bool interior = x0 - 1 >= 2 && x0 + UV_TX <= d.L - 2 && y0 - 1 >= 2 && y0 + UV_TY <= d.M - 2
-                          && y0 - 1 + d.joff >= 2 && y0 + UV_TY + d.joff <= d.Mg - 2;
+                          && y0 - 1 + d.joff >= 2 && y0 + UV_TY + d.joff <= d.Mg - 2 && tile_regular(d, x0, y0, UV_TY);
     for (int ilay = 1; ilay <= d.nlay; ++ilay) {
         if (interior) body_uv_fused<FIRST_X, true, true>(d, x0, y0, ilay, gene, ramp, ctim, s_h);
         else body_uv_fused<FIRST_X, true, false>(d, x0, y0, ilay, gene, ramp, ctim, s_h);
@@ -1405,7 +1412,9 @@ static inline dim3 muv_grid(const DevView &d) { return dim3(TileMap(d, UV_TX, UV
 // (a) layer fractions layt/layb/layu, cells 0..ndeg (the sentinel included, :1948,1972,1994)
 __global__ __launch_bounds__(BEOM_BLOCK) void k_stress_fractions(DevView d, int wind, int bot, int top) {
     const int ipnt = blockIdx.x * BEOM_BLOCK + threadIdx.x;     // 0..ndeg
-    if (!cell_slot(d, ipnt)) return;
+    // embedded frames: the land slots too — a coast cell's neighbour lookup must find there what the reference finds at
+    // index 0 (e.g. layb(0, nlay) = 1), and with hlay = 0 a land slot computes exactly the sentinel's fractions
+    if (!(d.embedded ? (ipnt <= d.ncell && (ipnt == 0 || (int)((ipnt - 1) % d.P) < d.L)) : cell_slot(d, ipnt))) return;
     const int nlay = d.nlay;
     if (wind || top) {
         for (int pass = 0; pass < 2; ++pass) {
@@ -1491,22 +1500,37 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_stress_apply(DevView d, int wind
 // ---- packed (the caller's Fortran storage) <-> padded device layout, one slice [0:ndeg] at a time ----
 // src/dst element = `inner` consecutive T; AoS histories: K interleaved levels, level m selected.
 // REMAP: the values themselves are cell indices (neig): translate them too.
+// slot_of (embedded frames): packed index -> slot of the rectangle; null: the dense closed form
 template <class T, bool TO_DEVICE, bool REMAP>
-__global__ __launch_bounds__(BEOM_BLOCK) void k_repack(T *dev, T *host_img, long long ndeg, int L, int P, int inner, int K, int m) {
+__global__ __launch_bounds__(BEOM_BLOCK) void k_repack(T *dev, T *host_img, long long ndeg, int L, int P, int inner, int K, int m,
+                                                       const int32_t *slot_of) {
     const long long t = (long long)blockIdx.x * BEOM_BLOCK + threadIdx.x;
     const long long n = (ndeg + 1) * inner;
     if (t >= n) return;
     const long long ip = t / inner;
     const int e = (int)(t - ip * inner);
     long long dp = ip;
-    if (ip > 0) { const long long r = (ip - 1) / L; dp = 1 + r * P + ((ip - 1) - r * L); }
+    if (slot_of) dp = slot_of[ip];
+    else if (ip > 0) { const long long r = (ip - 1) / L; dp = 1 + r * P + ((ip - 1) - r * L); }
     if (TO_DEVICE) {
         T v = host_img[(ip * inner + e) * K + m];
-        if (REMAP) { const long long q = (long long)v; if (q > 0) { const long long r = (q - 1) / L; v = (T)(1 + r * P + ((q - 1) - r * L)); } }
+        if (REMAP) {
+            const long long q = (long long)v;
+            if (q > 0) { if (slot_of) v = (T)slot_of[q]; else { const long long r = (q - 1) / L; v = (T)(1 + r * P + ((q - 1) - r * L)); } }
+        }
         dev[dp * inner + e] = v;
     } else {
         host_img[(ip * inner + e) * K + m] = dev[dp * inner + e];
     }
+}
+
+// embedded frames: every slot of a device slice <- the sentinel's element(s) of the caller's slice (land slots keep them)
+template <class T>
+__global__ __launch_bounds__(BEOM_BLOCK) void k_fill_sentinel(T *dev, const T *host_img, long long nslots, int inner, int K, int m) {
+    const long long t = (long long)blockIdx.x * BEOM_BLOCK + threadIdx.x;
+    if (t >= nslots * inner) return;
+    const int e = (int)(t % inner);
+    dev[t] = host_img[(long long)e * K + m];
 }
 
 // ---- ghost-row exchange support: rows [jlo, jlo+nrows) of hlay,u,v,h_u,h_v <-> one buffer ----

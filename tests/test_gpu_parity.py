@@ -95,7 +95,14 @@ def test_dense_detection(name):
     f = _fields(g)
     e = capi.Engine(f, variant=g.variant, dense_hint=1)
     full = g.p.ndeg == (g.p.lm + 1) * (g.p.mm + 1)
-    assert e.is_dense == full
+    assert (e.is_dense and not e.is_embedded) == full
+    # frames with land run on the same rectangle ("embedded") unless they use what only the table path has
+    # (open-boundary segments, biharmonic viscosity), the rectangle is mostly land, or a coast cell sits on a
+    # periodic seam (the reference wraps row by row there, :614-640: offsets cannot express that)
+    obc = bool(f.flag_nudging) and float(g.p.mcbc) < 0.5
+    periodic = float(g.p.xper) > 0.5 or float(g.p.yper) > 0.5
+    if not full and not obc and not periodic and float(g.p.svis) == 0.0 and g.p.ndeg * 10 >= (g.p.lm + 1) * (g.p.mm + 1) * 3:
+        assert e.is_embedded, name
     e.close()
 
 
@@ -178,6 +185,46 @@ def test_graph_replay_matches_oracle_and_eager(case):
         assert same(a[k], b[k]), (case, k, "graph vs eager")
         assert same(a[k], o.state()[k]), (case, k, "graph vs oracle")
     e.close(); plain.close()
+
+
+@pytest.mark.parametrize("case", ["island_leith", "island_wind_drag", "bay_ocrp_nudged"])
+def test_land_frames_on_the_rectangle_match_oracle_and_table_path(case):
+    """Frames WITH land wide enough to have regular tiles away from the coast: the embedded form (packed cells in the
+    slots of their (i, j), land slots holding the sentinel's values, masks from the caller's arrays in the tiles that
+    touch land, the fused mask-free paths elsewhere) against the oracle and against the table path, bit for bit."""
+    from beom_amd import inputs as I
+    from beom_amd.grid import read_input_data
+    if case == "island_leith":
+        p, files = I.case_headline(400, 130, 3)
+    elif case == "island_wind_drag":
+        p, files = I.case_stommel(lm=400, mm=130, dl=50.0e3, dt_s=0.2)
+        files = dict(files, h_bo=np.full((402, 132), 200.0))
+    else:
+        p, files = I.case_sill_exchange3d(lm=400, mm=130, nlay=3, dt_s=0.01, npts=5, sill_halfwidth=20.0)
+    files = {k: np.array(v, dtype=np.float64) for k, v in files.items()}
+    h = files["h_bo"]
+    x = np.arange(p.lm + 2)[:, None]; y = np.arange(p.mm + 2)[None, :]
+    land = ((x - 0.3 * p.lm) ** 2 + (y - 0.55 * p.mm) ** 2) < (0.12 * p.lm) ** 2          # an island
+    land |= (x > 0.8 * p.lm) & (y < 0.3 * p.mm) & ((x + y) % 7 != 0) if case == "bay_ocrp_nudged" else False   # a ragged corner
+    h[land] = 0.0
+    if "init" in files:
+        files["init"][land] = 0.0
+    p = p.replace(ndeg=I.get_nbr_deg_freedom(h))
+    f = read_input_data(p, files=files)
+    emb, tab, o = capi.Engine(f), capi.Engine(f, dense_hint=0), oracle_lib.Oracle(f)
+    assert emb.is_embedded and not tab.is_dense
+    for x_ in (emb, tab, o):
+        x_.step(1, 13)
+    a, b = emb.download(), tab.download()
+    for k in PROGNOSTIC:
+        assert same(a[k], o.state()[k]), (case, k, "embedded vs oracle", maxrel(a[k], o.state()[k]))
+        assert same(a[k], b[k]), (case, k, "embedded vs table path")
+    for k in ("hlay", "u", "v", "h_u", "h_v"):
+        assert same_bits(a[k], o.state()[k]), (case, k, "sign of zero")
+    eta, u4, v4, mm_, thin = emb.download_outputs(np.ascontiguousarray(f.h_0[:, 1:], dtype=np.float32))
+    eta2, u42, v42, mm2, thin2 = tab.download_outputs(np.ascontiguousarray(f.h_0[:, 1:], dtype=np.float32))
+    assert np.array_equal(eta.view(np.uint32), eta2.view(np.uint32)) and np.array_equal(mm_, mm2) and thin == thin2
+    emb.close(); tab.close()
 
 
 def test_restart_split_equals_single_run():
