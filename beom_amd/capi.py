@@ -144,6 +144,8 @@ def load(path: Optional[str] = None) -> C.CDLL:
     lib.beom_graph_stats.restype = ci
     lib.beom_set_open_boundaries.argtypes = [H, ci, ipp, cp, ci]
     lib.beom_download_outputs.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, dpp, C.POINTER(ci), cp, ci]
+    lib.beom_download_diag.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p, cp, ci]
+    lib.beom_download_diag.restype = ci
     lib.beom_step_phase.argtypes = [H, ci, cd, cd, cd, cd, ci, ci, cp, ci]
     lib.beom_pack_rows.argtypes = [H, ci, ci, C.c_void_p]
     lib.beom_unpack_rows.argtypes = [H, ci, ci, C.c_void_p]
@@ -171,6 +173,8 @@ def load(path: Optional[str] = None) -> C.CDLL:
     lib.beom_multi_sync.argtypes = [MH, cp, ci]
     lib.beom_multi_stats.argtypes = [MH, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     lib.beom_multi_create_ex.argtypes = [C.POINTER(BeomParams), ci, C.POINTER(ci), ci, ipp, ipp] + [dpp] * 14 + [C.POINTER(MH), cp, ci]
+    lib.beom_multi_download_outputs.argtypes = [MH, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, dpp, C.POINTER(ci), cp, ci]
+    lib.beom_multi_download_diag.argtypes = [MH, C.c_void_p, C.c_void_p, C.c_void_p, cp, ci]
     lib.beom_multi_describe.argtypes = [MH] + [C.POINTER(ci)] * 5
     lib.beom_multi_set_option.argtypes = [MH, cp, ci]
     lib.beom_multi_engine.argtypes = [MH, ci, C.POINTER(H)]
@@ -186,6 +190,7 @@ def load(path: Optional[str] = None) -> C.CDLL:
     for name in ("beom_multi_create", "beom_multi_destroy", "beom_multi_count", "beom_multi_band",
                  "beom_multi_upload_state", "beom_multi_download_state", "beom_multi_step", "beom_multi_sync",
                  "beom_multi_stats", "beom_multi_create_ex", "beom_multi_describe", "beom_multi_engine",
+                 "beom_multi_download_outputs", "beom_multi_download_diag",
                  "beom_multi_set_option", "beom_multi_profile_start", "beom_multi_profile_stop", "beom_rccl_unique_id", "beom_rccl_version",
                  "beom_multi_window", "beom_multi_create_local", "beom_multi_upload_local", "beom_multi_download_local"):
         getattr(lib, name).restype = ci
@@ -203,7 +208,7 @@ def load(path: Optional[str] = None) -> C.CDLL:
     return lib
 
 
-EXPORTS = ("beom_abi_version", "beom_device_count", "beom_device_pci_bus_id", "beom_graph_stats", "beom_create", "beom_destroy",
+EXPORTS = ("beom_abi_version", "beom_device_count", "beom_device_pci_bus_id", "beom_graph_stats", "beom_download_diag", "beom_create", "beom_destroy",
            "beom_upload_state", "beom_download_state", "beom_download_scratch", "beom_step",
            "beom_sync", "beom_update_h", "beom_update_mont_rvor_pvor_dive_kine",
            "beom_update_viscosity", "beom_update_u", "beom_update_v", "beom_rebuild_fluxes",
@@ -214,6 +219,7 @@ EXPORTS = ("beom_abi_version", "beom_device_count", "beom_device_pci_bus_id", "b
            "beom_multi_create", "beom_multi_destroy", "beom_multi_count", "beom_multi_band",
            "beom_multi_upload_state", "beom_multi_download_state", "beom_multi_step", "beom_multi_sync",
            "beom_multi_stats", "beom_multi_create_ex", "beom_multi_describe", "beom_multi_engine",
+           "beom_multi_download_outputs", "beom_multi_download_diag",
            "beom_multi_set_option", "beom_multi_profile_start", "beom_multi_profile_stop", "beom_rccl_unique_id", "beom_rccl_version",
            "beom_multi_window", "beom_multi_create_local", "beom_multi_upload_local", "beom_multi_download_local")
 
@@ -330,6 +336,13 @@ class Engine:
                                                    u4.ctypes.data_as(C.c_void_p), v4.ctypes.data_as(C.c_void_p),
                                                    _dp(mm), C.byref(thin), self._err, ERRLEN))
         return eta, u4, v4, mm, thin.value
+
+    def download_diag(self):
+        """(pvor, mont, v_cc) real*4 records [nlay, ndeg] of write_array's `diag` branch, formed on the device."""
+        n = (self.p.nlay, self.p.ndeg)
+        out = [np.zeros(n, dtype=np.float32) for _ in range(3)]
+        self._check(self.lib.beom_download_diag(self.h, *[a.ctypes.data_as(C.c_void_p) for a in out], self._err, ERRLEN))
+        return tuple(out)
 
     def set_option(self, name: str, value: int):
         self._check(self.lib.beom_set_option(self.h, name.encode(), int(value)))
@@ -469,6 +482,23 @@ class MultiEngine:
         a, b = C.c_longlong(), C.c_longlong()
         self.lib.beom_multi_stats(self.h, C.byref(a), C.byref(b))
         return {"split": a.value, "plain": b.value}
+
+    def download_outputs(self, h0r4: np.ndarray):
+        """(eta, u, v) real*4 records [nlay, ndeg], minmax [nlay, 6], thin_layer — every band forms its rows on its device."""
+        n = (self.p.nlay, self.p.ndeg)
+        eta, u4, v4 = (np.zeros(n, dtype=np.float32) for _ in range(3))
+        mm = np.zeros((self.p.nlay, 6))
+        thin = C.c_int(0)
+        self._check(self.lib.beom_multi_download_outputs(self.h, h0r4.ctypes.data_as(C.c_void_p), eta.ctypes.data_as(C.c_void_p),
+                                                         u4.ctypes.data_as(C.c_void_p), v4.ctypes.data_as(C.c_void_p),
+                                                         _dp(mm), C.byref(thin), self._err, ERRLEN))
+        return eta, u4, v4, mm, thin.value
+
+    def download_diag(self):
+        n = (self.p.nlay, self.p.ndeg)
+        out = [np.zeros(n, dtype=np.float32) for _ in range(3)]
+        self._check(self.lib.beom_multi_download_diag(self.h, *[a.ctypes.data_as(C.c_void_p) for a in out], self._err, ERRLEN))
+        return tuple(out)
 
     def describe(self) -> dict:
         v = [C.c_int() for _ in range(5)]

@@ -62,6 +62,7 @@ struct beom_engine {
     dim3 grid_cells0, grid_cells_layers_flat;
     bool wind = false, bot = false, top = false;
     float *h0r4_dev = nullptr, *out4[3] = {nullptr, nullptr, nullptr};   // device-side output staging
+    float *diag4[3] = {nullptr, nullptr, nullptr};
     double *scan_dev = nullptr;
     int any_u = 0, any_v = 0;
     long long uniform_waves = 0, total_waves = 0;   // table path: runs of 64 cells handled by offset arithmetic
@@ -1061,6 +1062,27 @@ int beom_download_outputs(beom_handle E, const float *h0r4, float *eta, float *u
             if (thin_layer && r[6] > 0.5 && *thin_layer == 0) *thin_layer = k + 1;
         }
     }
+    HIP_TRY(hipStreamSynchronize(E->stream));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// The three `diag` records of write_array (private_mod.f95:2884-2974) formed on the device: only real*4 crosses PCIe.
+// Between time steps only (the work arrays are the step's d2hx / d2hy scratch).
+int beom_download_diag(beom_handle E, float *pvor4, float *mont4, float *vcc4, char *errm, int errm_len) {
+    if (!E) { set_err(errm, errm_len, "null handle"); return -1; }
+    HIP_TRY(hipSetDevice(E->device));
+    DevView &d = E->d;
+    const size_t n = (size_t)d.ndeg * d.nlay;
+    float *dst[3] = {pvor4, mont4, vcc4};
+    if (!E->diag4[0])
+        for (int q = 0; q < 3; ++q) { HIP_TRY(hipMalloc((void **)&E->diag4[q], n * sizeof(float))); E->allocs.push_back(E->diag4[q]); }
+    const dim3 g = E->grid_cells_layers_flat, b(BEOM_BLOCK);
+    if (vcc4) hipLaunchKernelGGL(k_diag_w12, g, b, 0, E->stream, d, d.d2hx, d.d2hy);
+    hipLaunchKernelGGL(k_diag_records, g, b, 0, E->stream, d, (const double *)d.d2hx, (const double *)d.d2hy,
+                       pvor4 ? E->diag4[0] : nullptr, mont4 ? E->diag4[1] : nullptr, vcc4 ? E->diag4[2] : nullptr);
+    for (int q = 0; q < 3; ++q)
+        if (dst[q]) HIP_TRY(hipMemcpyAsync(dst[q], E->diag4[q], n * sizeof(float), hipMemcpyDeviceToHost, E->stream));
     HIP_TRY(hipStreamSynchronize(E->stream));
     HIP_TRY(hipGetLastError());
     return 0;

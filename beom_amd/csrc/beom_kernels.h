@@ -1572,6 +1572,51 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_out_convert(DevView d, const flo
     }
 }
 
+// ---- the three `diag` records of write_array (private_mod.f95:2884-2974), real*4 (ndeg, nlay) packed: the Leith
+//      viscosity diagnosed from u, v ('v_cc'), the Montgomery potential without its kinetic part ('mont') and the
+//      potential vorticity ('pvor').  They are NOT the step's own scratch fields (other operation order, real*4
+//      accumulation), so they are formed here from the state, with the caller's neig and mask arrays.
+__global__ __launch_bounds__(BEOM_BLOCK) void k_diag_w12(DevView d, double *w1, double *w2) {      // :2892-2904
+    const int ipnt = blockIdx.x * BEOM_BLOCK + threadIdx.x + 1;
+    const int ilay = blockIdx.y + 1;
+    if (!cell_slot(d, ipnt)) return;
+    const int32_t *nb = d.neig + 8ll * ipnt;
+    const int c1 = nb[0], c3 = nb[2], c5 = nb[4], c7 = nb[6];
+    LL(w1, ipnt, ilay) = ((LL(d.v, ipnt, ilay) - LL(d.v, c5, ilay)) / d.dl - (LL(d.u, ipnt, ilay) - LL(d.u, c7, ilay)) / d.dl) * d.mkpe[ipnt];
+    LL(w2, ipnt, ilay) = (LL(d.u, c1, ilay) - LL(d.u, ipnt, ilay)) / d.dl + (LL(d.v, c3, ilay) - LL(d.v, ipnt, ilay)) / d.dl;
+}
+__global__ __launch_bounds__(BEOM_BLOCK) void k_diag_records(DevView d, const double *w1, const double *w2, float *pvor4, float *mont4,
+                                                              float *vcc4) {
+    const int ipnt = blockIdx.x * BEOM_BLOCK + threadIdx.x + 1;
+    const int ilay = blockIdx.y + 1;
+    if (!cell_slot(d, ipnt)) return;
+    const long long o = packed_index0(d, ipnt) + (long long)d.ndeg * (ilay - 1);
+    const int32_t *nb = d.neig + 8ll * ipnt;
+    const int c1 = nb[0], c2 = nb[1], c3 = nb[2], c5 = nb[4], c6 = nb[5], c7 = nb[6];
+    if (vcc4) {                                                                                      // :2906-2927
+        const double a0 = LL(w1, ipnt, ilay), a1 = LL(w1, c1, ilay), a2 = LL(w1, c2, ilay), a3 = LL(w1, c3, ilay);
+        const double b0 = LL(w2, ipnt, ilay), b1 = LL(w2, c1, ilay), b3 = LL(w2, c3, ilay), b5 = LL(w2, c5, ilay), b7 = LL(w2, c7, ilay);
+        const double q = (a1 - a0) * (a1 - a0) + (a2 - a3) * (a2 - a3) + (a3 - a0) * (a3 - a0) + (a2 - a1) * (a2 - a1)
+                       + (b1 - b0) * (b1 - b0) + (b0 - b5) * (b0 - b5) + (b3 - b0) * (b3 - b0) + (b0 - b7) * (b0 - b7);
+        vcc4[o] = (float)(d.bvis + d.dvis * (d.dl * d.dl) * sqrt(q));
+    }
+    if (mont4) {                                                                                     // :2930-2950
+        const double mkn = d.mk_n[ipnt];
+        float a = (float)(-(d.ocrp / (double)(d.nsal - 1) * d.hsal * mkn
+                            * powi_dev(d.hsal / (d.hmin * (1.0 - mkn) + LL(d.hlay, ipnt, ilay)), d.nsal - 1)));
+        for (int m = 1; m <= ilay - 1; ++m)
+            a = a - (float)((d.rhon[ilay - 1] - d.rhon[m - 1]) * LL(d.hlay, ipnt, m) / d.rhon[ilay - 1]);
+        double hsum = 0.0;                                                 // sum( hlay(ipnt, :) ): left to right
+        for (int m = 1; m <= d.nlay; ++m) hsum = m == 1 ? LL(d.hlay, ipnt, 1) : hsum + LL(d.hlay, ipnt, m);
+        mont4[o] = a + (float)(hsum - d.h_th[ipnt]);
+    }
+    if (pvor4) {                                                                                     // :2951-2974
+        const double zeta = ((LL(d.v, ipnt, ilay) - LL(d.v, c5, ilay)) / d.dl - (LL(d.u, ipnt, ilay) - LL(d.u, c7, ilay)) / d.dl) * d.mkpe[ipnt];
+        pvor4[o] = (float)((d.fcor[ipnt] + zeta * d.uadv) * d.mkpi[ipnt] * (d.mk_n[ipnt] + d.mk_n[c5] + d.mk_n[c7] + d.mk_n[c6])
+                           / (LL(d.hlay, ipnt, ilay) + LL(d.hlay, c5, ilay) + LL(d.hlay, c6, ilay) + LL(d.hlay, c7, ilay)));
+    }
+}
+
 // per-workgroup partial min/max of h (wet cells), u, v (their points, or all cells 0..ndeg when a
 // mask is empty, :2776-2793) and the thin-layer flag (:2799-2800); the host reduces the partials.
 // out: [block][layer][7] = hmin,hmax,umin,umax,vmin,vmax,thin

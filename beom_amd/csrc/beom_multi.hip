@@ -23,6 +23,7 @@
 
 #include <dlfcn.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -673,6 +674,88 @@ int beom_multi_download_state(beom_multi_handle M, double *hlay, double *u, doub
         else { const Band &s = M->band[k]; j0 = s.gs + 1; n = s.nown(); for (int j = 0; j < n; ++j) rows.push_back(s.own0 + j); }
         for (int f = 0; f < 13; ++f)
             paste(dst[f], a.a[f], kState[f].outer(nl), kState[f].inner, n1g, n1l, L, j0, n, rows, k == 0);
+    }
+    return 0;
+}
+
+// ---- output records of all bands (SURVEY §8f N2 for the multi-device handle): as beom_download_outputs /
+//      beom_download_diag with GLOBAL (ndeg, nlay) real*4 records; every band forms its rows on its device.
+namespace {
+// (ndeg, nlay) records have no sentinel: cell (row r, column i) of layer k at (i-1) + (r-1)*L + ndeg*(k-1)
+std::vector<float> cut_rec(const float *x, int nl, size_t ndeg_g, const std::vector<int> &rows, int L) {
+    std::vector<float> z;
+    if (!x) return z;
+    const size_t nloc = rows.size() * (size_t)L;
+    z.resize(nloc * nl);
+    for (int k = 0; k < nl; ++k)
+        for (size_t r = 0; r < rows.size(); ++r)
+            std::memcpy(&z[k * nloc + r * L], &x[k * ndeg_g + (size_t)(rows[r] - 1) * L], (size_t)L * sizeof(float));
+    return z;
+}
+void paste_rec(float *dst, const std::vector<float> &loc, int nl, size_t ndeg_g, size_t nloc, int L, int j0, int n,
+               const std::vector<int> &dst_rows) {
+    if (!dst || loc.empty()) return;
+    for (int k = 0; k < nl; ++k)
+        for (int r = 0; r < n; ++r)
+            std::memcpy(&dst[k * ndeg_g + (size_t)(dst_rows[r] - 1) * L], &loc[k * nloc + (size_t)(j0 - 1 + r) * L], (size_t)L * sizeof(float));
+}
+}  // namespace
+
+int beom_multi_download_outputs(beom_multi_handle M, const float *h0r4, float *eta, float *u4, float *v4,
+                                double *minmax, int *thin_layer, char *errm, int errm_len) {
+    if (!M) { m_err(errm, errm_len, "null handle"); return -1; }
+    if (M->local_mode) { m_err(errm, errm_len, "beom_multi_download_outputs: this handle holds a window"); return -3; }
+    if (!h0r4) { m_err(errm, errm_len, "beom_multi_download_outputs: h_0 (real*4) is needed"); return -3; }
+    M_RC(beom_multi_sync(M, errm, errm_len));
+    if (M->nb == 1 && !M->ring) return beom_download_outputs(M->eng[0], h0r4, eta, u4, v4, minmax, thin_layer, errm, errm_len);
+    const int nl = M->P.nlay, L = M->P.lm + 1;
+    const size_t ndeg_g = (size_t)M->P.ndeg;
+    if (thin_layer) *thin_layer = 0;
+    for (int k = -1; k < M->n; ++k) {
+        if (k < 0 && !M->mini) continue;
+        const std::vector<int> rows = k < 0 ? M->mini_rows : M->band[k].row_list();
+        const size_t nloc = rows.size() * (size_t)L;
+        std::vector<float> h0 = cut_rec(h0r4, nl, ndeg_g, rows, L), e(eta ? nloc * nl : 0), a(u4 ? nloc * nl : 0), b(v4 ? nloc * nl : 0);
+        std::vector<double> mm((size_t)nl * 6);
+        int thin = 0;
+        M_RC(beom_download_outputs(k < 0 ? M->mini : M->eng[k], h0.data(), ptr(e), ptr(a), ptr(b), mm.data(), &thin, errm, errm_len));
+        int j0, n;
+        std::vector<int> dst_rows;
+        if (k < 0) { j0 = (int)rows.size(); n = 1; dst_rows.push_back(M->P.mm + 1); }       // the orphan row; its scans are not merged
+        else { const Band &s = M->band[k]; j0 = s.gs + 1; n = s.nown(); for (int j = 0; j < n; ++j) dst_rows.push_back(s.own0 + j); }
+        paste_rec(eta, e, nl, ndeg_g, nloc, L, j0, n, dst_rows);
+        paste_rec(u4, a, nl, ndeg_g, nloc, L, j0, n, dst_rows);
+        paste_rec(v4, b, nl, ndeg_g, nloc, L, j0, n, dst_rows);
+        if (k < 0) continue;
+        // a band's scans cover its ghost rows too: they hold the neighbours' owned values (the exchange has landed)
+        if (minmax)
+            for (int q = 0; q < nl * 6; ++q)
+                minmax[q] = (k == 0) ? mm[q] : ((q % 2 == 0) ? std::fmin(minmax[q], mm[q]) : std::fmax(minmax[q], mm[q]));
+        if (thin_layer && thin > 0 && (*thin_layer == 0 || thin < *thin_layer)) *thin_layer = thin;
+    }
+    return 0;
+}
+
+int beom_multi_download_diag(beom_multi_handle M, float *pvor4, float *mont4, float *vcc4, char *errm, int errm_len) {
+    if (!M) { m_err(errm, errm_len, "null handle"); return -1; }
+    if (M->local_mode) { m_err(errm, errm_len, "beom_multi_download_diag: this handle holds a window"); return -3; }
+    M_RC(beom_multi_sync(M, errm, errm_len));
+    if (M->nb == 1 && !M->ring) return beom_download_diag(M->eng[0], pvor4, mont4, vcc4, errm, errm_len);
+    const int nl = M->P.nlay, L = M->P.lm + 1;
+    const size_t ndeg_g = (size_t)M->P.ndeg;
+    for (int k = -1; k < M->n; ++k) {
+        if (k < 0 && !M->mini) continue;
+        const std::vector<int> rows = k < 0 ? M->mini_rows : M->band[k].row_list();
+        const size_t nloc = rows.size() * (size_t)L;
+        std::vector<float> a(pvor4 ? nloc * nl : 0), b(mont4 ? nloc * nl : 0), c(vcc4 ? nloc * nl : 0);
+        M_RC(beom_download_diag(k < 0 ? M->mini : M->eng[k], ptr(a), ptr(b), ptr(c), errm, errm_len));
+        int j0, n;
+        std::vector<int> dst_rows;
+        if (k < 0) { j0 = (int)rows.size(); n = 1; dst_rows.push_back(M->P.mm + 1); }
+        else { const Band &s = M->band[k]; j0 = s.gs + 1; n = s.nown(); for (int j = 0; j < n; ++j) dst_rows.push_back(s.own0 + j); }
+        paste_rec(pvor4, a, nl, ndeg_g, nloc, L, j0, n, dst_rows);
+        paste_rec(mont4, b, nl, ndeg_g, nloc, L, j0, n, dst_rows);
+        paste_rec(vcc4, c, nl, ndeg_g, nloc, L, j0, n, dst_rows);
     }
     return 0;
 }

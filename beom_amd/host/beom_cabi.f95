@@ -99,6 +99,34 @@ module beom_cabi
       integer(c_int)           :: rc
     end function beom_download_outputs
 
+    function beom_multi_download_outputs(handle, h0r4, eta, u4, v4, minmax, thin_layer, errm, errm_len)  &
+             bind(C, name = 'beom_multi_download_outputs') result(rc)
+      import :: c_int, c_ptr, c_char
+      type(c_ptr), value       :: handle, h0r4, eta, u4, v4, minmax
+      integer(c_int)           :: thin_layer
+      character(kind = c_char) :: errm(*)
+      integer(c_int), value    :: errm_len
+      integer(c_int)           :: rc
+    end function beom_multi_download_outputs
+
+    function beom_multi_download_diag(handle, pvor, mont, v_cc, errm, errm_len)                          &
+             bind(C, name = 'beom_multi_download_diag') result(rc)
+      import :: c_int, c_ptr, c_char
+      type(c_ptr), value       :: handle, pvor, mont, v_cc
+      character(kind = c_char) :: errm(*)
+      integer(c_int), value    :: errm_len
+      integer(c_int)           :: rc
+    end function beom_multi_download_diag
+
+    function beom_download_diag(handle, pvor, mont, v_cc, errm, errm_len)                                &
+             bind(C, name = 'beom_download_diag') result(rc)
+      import :: c_int, c_ptr, c_char
+      type(c_ptr), value       :: handle, pvor, mont, v_cc
+      character(kind = c_char) :: errm(*)
+      integer(c_int), value    :: errm_len
+      integer(c_int)           :: rc
+    end function beom_download_diag
+
     function beom_set_open_boundaries(handle, nseg, segm, errm, errm_len)                                &
              bind(C, name = 'beom_set_open_boundaries') result(rc)
       import :: c_int, c_ptr, c_char

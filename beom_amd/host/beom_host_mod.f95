@@ -868,13 +868,29 @@ subroutine write_outputs_from_gpu()
   p_h0 = c_null_ptr
   if ( .not. h0_on_gpu ) p_h0 = c_loc(h0r4)
   thin = 0
-  rc = beom_download_outputs( gpu, p_h0, c_loc(rec_eta), c_loc(rec_u), c_loc(rec_v), c_loc(mnmx), thin, &
-                              cmsg, int(lstr, c_int) )
+  if ( ngpu > 1 ) then                                           ! every band forms its own rows on its device
+    rc = beom_multi_download_outputs( gpus, c_loc(h0r4), c_loc(rec_eta), c_loc(rec_u), c_loc(rec_v), c_loc(mnmx), thin, &
+                                      cmsg, int(lstr, c_int) )
+  else
+    rc = beom_download_outputs( gpu, p_h0, c_loc(rec_eta), c_loc(rec_u), c_loc(rec_v), c_loc(mnmx), thin, &
+                                cmsg, int(lstr, c_int) )
+  end if
   call gpu_check( rc, cmsg, 'beom_download_outputs' )
   h0_on_gpu = .true.
   call put_record_r4( 'eta_.bin', out_rec, rec_eta, .false. )
   call put_record_r4( 'u___.bin', out_rec, rec_u,   .false. )
   call put_record_r4( 'v___.bin', out_rec, rec_v,   .false. )
+  if ( diag > 0.5_rw ) then                                      ! pvor, mont, v_cc (:2884-2974) formed on the device too
+    if ( ngpu > 1 ) then
+      rc = beom_multi_download_diag( gpus, c_loc(rec_eta), c_loc(rec_u), c_loc(rec_v), cmsg, int(lstr, c_int) )
+    else
+      rc = beom_download_diag( gpu, c_loc(rec_eta), c_loc(rec_u), c_loc(rec_v), cmsg, int(lstr, c_int) )
+    end if
+    call gpu_check( rc, cmsg, 'beom_download_diag' )
+    call put_record_r4( 'pvor.bin', out_rec, rec_eta, .false. )
+    call put_record_r4( 'mont.bin', out_rec, rec_u,   .false. )
+    call put_record_r4( 'v_cc.bin', out_rec, rec_v,   .false. )
+  end if
   unum = get_un()
   open( unit = unum, file = trim(odir) // 'time.txt', form = 'formatted', action = 'write', status = 'old', &
         position = 'append', iostat = ios )
@@ -1068,21 +1084,7 @@ subroutine advance()
     call gpu_check( rc, cmsg, 'beom_step' )
     if ( mod(last, notp) == 0 ) then
       ctim = real( tres + dtd8 * real(last, r8), rw )
-      if ( ngpu > 1 ) then                                       ! gather the owned rows of every band
-        rc = beom_multi_download_state( gpus, c_loc(hlay), c_loc(u), c_loc(v), c_null_ptr, c_null_ptr, c_null_ptr, &
-                                        c_null_ptr, c_null_ptr, c_null_ptr, c_null_ptr, c_null_ptr, c_null_ptr,  &
-                                        c_null_ptr, cmsg, int(lstr, c_int) )
-        call gpu_check( rc, cmsg, 'beom_multi_download_state' )
-        call write_outputs()
-      else if ( diag > 0.5_rw ) then                                  ! pvor/mont/v_cc are diagnosed on the host
-        rc = beom_download_state( gpu, c_loc(hlay), c_loc(u), c_loc(v), c_null_ptr, c_null_ptr, c_null_ptr, &
-                                  c_null_ptr, c_null_ptr, c_null_ptr, c_null_ptr, c_null_ptr, c_null_ptr,  &
-                                  c_null_ptr, cmsg, int(lstr, c_int) )
-        call gpu_check( rc, cmsg, 'beom_download_state' )
-        call write_outputs()
-      else
-        call write_outputs_from_gpu()                            ! only real*4 records cross PCIe
-      end if
+      call write_outputs_from_gpu()                              ! only real*4 records cross PCIe (one or several devices)
     end if
     first = last + 1
   end do

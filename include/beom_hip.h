@@ -132,6 +132,11 @@ int beom_download_state(beom_handle h,
 int beom_download_outputs(beom_handle h, const float *h0r4, float *eta, float *u4, float *v4,
                           double *minmax, int *thin_layer, char *errm, int errm_len);
 
+/* The `diag` records of write_array (private_mod.f95:2884-2974), formed on the device from the state: 'pvor', 'mont'
+ * (without the kinetic part, real*4 accumulation as in the reference) and 'v_cc' (Leith viscosity diagnosed from u, v) —
+ * each (ndeg, nlay) real*4, any pointer may be NULL.  Call between time steps (uses the step's scratch arrays). */
+int beom_download_diag(beom_handle h, float *pvor, float *mont, float *v_cc, char *errm, int errm_len);
+
 /* The six per-layer diagnostics of update_mont_rvor_pvor_dive_kine, which the library
  * keeps per layer: each is (0:ndeg, nlay).  (The reference keeps (0:ndeg) and reuses it
  * layer after layer, private_mod.f95:48-61.) */
@@ -282,6 +287,11 @@ int beom_multi_download_state(beom_multi_handle h,
                               double *v_cc, double *v_ll,
                               double *tt3d, double *tb3d, double *tu3d,
                               char *errm, int errm_len);
+/* as beom_download_outputs / beom_download_diag: GLOBAL (ndeg, nlay) real*4 records, every band forming its own rows on
+ * its device (h_0 is needed on every call here); global-array handles only */
+int beom_multi_download_outputs(beom_multi_handle h, const float *h0r4, float *eta, float *u4, float *v4,
+                                double *minmax, int *thin_layer, char *errm, int errm_len);
+int beom_multi_download_diag(beom_multi_handle h, float *pvor, float *mont, float *v_cc, char *errm, int errm_len);
 int beom_multi_step(beom_multi_handle h, int tstp_first, int nsteps,
                     double tres, double dtd8, double dt_r, double rsta, int n_3d,
                     char *errm, int errm_len);

@@ -645,6 +645,47 @@ def test_one_process_several_bands_match_single_handle(case, nband):
     one.close(); many.close()
 
 
+@pytest.mark.parametrize("case,nband", [("closed", 3), ("jet_ring", 2), ("sill_nudged", 2)])
+def test_output_and_diag_records_of_bands_match_single_handle(case, nband):
+    """write_array's records (eta_, u___, v___ and the diag trio pvor, mont, v_cc; private_mod.f95:2848-2974), min/max
+    and the thin-layer scan formed on the devices of a frame cut into bands == those of the single handle, bit for bit;
+    the single handle's diag records == a numpy restatement of the reference's expressions."""
+    from beom_amd import inputs as I
+    from beom_amd.grid import read_input_data
+    p, files = {"closed": lambda: I.case_headline(150, 260, 3),
+                "jet_ring": lambda: I.case_unstable_jet(lm=131, mm=151, nlay=2, dt_s=1.5),
+                "sill_nudged": lambda: I.case_sill_exchange3d(lm=133, mm=199, nlay=4, dt_s=0.01, npts=5, sill_halfwidth=20.0)}[case]()
+    f = read_input_data(p, files=files)
+    one, many = capi.Engine(f), capi.MultiEngine(f, devices=[0] * nband)
+    one.step(1, 9); many.step(1, 9)
+    h0 = np.ascontiguousarray(f.h_0[:, 1:], dtype=np.float32)
+    a, b = one.download_outputs(h0), many.download_outputs(h0)
+    for x, y, nm in zip(a[:3], b[:3], ("eta", "u", "v")):
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), (case, nm)
+    assert np.array_equal(a[3], b[3]) and a[4] == b[4], (case, "minmax / thin layer")
+    da, db = one.download_diag(), many.download_diag()
+    for x, y, nm in zip(da, db, ("pvor", "mont", "v_cc")):
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), (case, nm)
+    # the reference's expressions in numpy (float64 state -> real*4 records)
+    st = one.download(("hlay", "u", "v"))
+    nb = f.neig.astype(np.int64)
+    c1, c2, c3, c5, c6, c7 = (nb[:, k] for k in (0, 1, 2, 4, 5, 6))
+    dl = float(p.dl)
+    for k in range(p.nlay):
+        u, v, h = st["u"][k], st["v"][k], st["hlay"][k]
+        w1 = ((v - v[c5]) / dl - (u - u[c7]) / dl) * f.mkpe
+        w2 = (u[c1] - u) / dl + (v[c3] - v) / dl
+        q = ((w1[c1] - w1) ** 2 + (w1[c2] - w1[c3]) ** 2 + (w1[c3] - w1) ** 2 + (w1[c2] - w1[c1]) ** 2
+             + (w2[c1] - w2) ** 2 + (w2 - w2[c5]) ** 2 + (w2[c3] - w2) ** 2 + (w2 - w2[c7]) ** 2)
+        vcc = (float(p.bvis) + float(p.dvis) * (dl * dl) * np.sqrt(q)).astype(np.float32)
+        assert np.array_equal(vcc[1:].view(np.uint32), da[2][k].view(np.uint32)), (case, "v_cc", k)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            pv = ((f.fcor + w1 * float(p.uadv)) * f.mkpi * (f.mk_n + f.mk_n[c5] + f.mk_n[c7] + f.mk_n[c6])
+                  / (h + h[c5] + h[c6] + h[c7])).astype(np.float32)
+        assert np.array_equal(pv[1:].view(np.uint32), da[0][k].view(np.uint32)), (case, "pvor", k)
+    one.close(); many.close()
+
+
 def test_multi_refuses_what_it_cannot_split():
     from beom_amd import inputs as I
     from beom_amd.grid import read_input_data
