@@ -55,6 +55,11 @@ class Fields:
     flag_nudging: bool
     has: Dict[str, bool]  # which optional input files were present
     segm: Optional[np.ndarray] = None   # int32 [18, nseg] = Fortran segm(nseg, 18): nudged open-boundary segments
+    # rigid lid (rgld = 1, private_mod.f95:505-563): surface pressure and the operators of its Poisson equation, f8 [ndeg+1]
+    pi_s: Optional[np.ndarray] = None
+    Ow: Optional[np.ndarray] = None
+    Os: Optional[np.ndarray] = None
+    Osum_: Optional[np.ndarray] = None
 
     @property
     def ndeg(self): return self.p.ndeg
@@ -345,6 +350,41 @@ def equilibrium_h0_ocrp(p: Params, g, h_2d, dmax=None) -> np.ndarray:
     return h_0
 
 
+def rigid_lid_operators(p: Params, g, h_0: np.ndarray):
+    """private_mod.f95:505-563 — start value of the lid pressure and the operators Ow, Os, 1/Osum of its Poisson
+    equation.  In the reference this block sits at the end of get_equilibrium_thickness_h_0, i.e. it only runs
+    with ocrp = 1; otherwise all four stay zero (and the pressure solve is a no-op)."""
+    n1 = p.ndeg + 1
+    z = lambda: np.zeros(n1, dtype=f8)
+    pi_s, Ow, Os, Osum, Osum_ = z(), z(), z(), z(), z()
+    if p.ocrp < 0.5:
+        return pi_s, Ow, Os, Osum_
+    lm, mm = p.lm, p.mm
+    h_th, neig = g["h_th"], g["neig"].astype(np.int64)
+    i, j = g["subc"][0].astype(np.int64), g["subc"][1].astype(np.int64)
+    c1, c3, c5, c7 = neig[:, 0], neig[:, 2], neig[:, 4], neig[:, 6]
+    pi_s[:] = (_seq_sum(h_0, 0) - h_th) * p.grav                          # :509, index 0 included
+    dl2 = p.dl * p.dl
+    hw = 0.5 * (h_th + h_th[c5])
+    hs = 0.5 * (h_th + h_th[c7])
+    a = (1 < i) & (i < lm + 1) & (1 < j) & (j < mm + 1)
+    b = (i == 1) & (1 < j) & (j < mm + 1)
+    c = (1 < i) & (i < lm + 1) & (j == 1)
+    Ow[:] = np.where(a | c, hw / dl2, 0.0)
+    Os[:] = np.where(a | b, hs / dl2, 0.0)
+    Ow[0] = 0.0; Os[0] = 0.0
+    s1 = ((Ow + Ow[c1]) + Os) + Os[c3]
+    s2 = (Ow + Os) + Os[c3]
+    s3 = (Ow + Os) + Ow[c1]
+    s4 = Ow + Os
+    Osum[:] = np.where((i < lm) & (j < mm), s1, np.where((i == lm) & (j < mm), s2, np.where((j == mm) & (i < lm), s3, s4)))
+    inside = (i > 0) & (i < lm + 1) & (j > 0) & (j < mm + 1)
+    with np.errstate(divide="ignore"):
+        Osum_[:] = np.where(inside, 1.0 / Osum, 0.0)
+    Osum_[0] = 0.0
+    return pi_s, Ow, Os, Osum_
+
+
 def _unpack(arr2d: np.ndarray, subc: np.ndarray) -> np.ndarray:
     out = np.zeros(subc.shape[1], dtype=arr2d.dtype)
     out[1:] = arr2d[subc[0, 1:], subc[1, 1:]]
@@ -404,6 +444,7 @@ def read_input_data(p: Params, idir: Optional[str] = None,
         h_0 = equilibrium_h0_noocrp(p, g, h_2d, dmax)
     else:
         h_0 = equilibrium_h0_ocrp(p, g, h_2d, dmax)
+    rl = rigid_lid_operators(p, g, h_0) if p.rgld > 0.5 else (None, None, None, None)
     z2 = lambda: np.zeros((nlay, ndeg + 1), dtype=f8)
     hlay = h_0 * g["mk_n"][None, :]                                 # :198-200
     u, v = z2(), z2()
@@ -500,4 +541,5 @@ def read_input_data(p: Params, idir: Optional[str] = None,
         tt3d=np.zeros((nlay, 2, ndeg + 1), dtype=f8), tb3d=np.zeros((nlay, 2, ndeg + 1), dtype=f8),
         tu3d=np.zeros((nlay, 2, ndeg + 1), dtype=f8), taus=taus,
         fnud=fnud, nudg=nudg, hdot=hdot, tide=tide, w_ti=w_ti, bodf=bodf,
-        invf=float(invf), flag_nudging=flag_nudging, has=has, segm=segm)
+        invf=float(invf), flag_nudging=flag_nudging, has=has, segm=segm,
+        pi_s=rl[0], Ow=rl[1], Os=rl[2], Osum_=rl[3])

@@ -35,6 +35,10 @@ typedef struct oracle_state {
     int64_t nseg;
     /* biharmonic viscosity work arrays (0:ndeg, nlay), needed when svis > 0 (private_mod.f95:40-43) */
     double *delu, *delv, *uu4, *vv4;
+    /* rigid lid (rgld = 1): surface pressure pi_s(0:ndeg) and the operators of its Poisson equation
+     * (private_mod.f95:64-67, 91, 505-563); needed when rgld > 0.5 */
+    double *pi_s;
+    const double *Ow, *Os, *Osum_;
 } oracle_state;
 
 #define N1 ((size_t)P->ndeg + 1)
@@ -504,12 +508,110 @@ void oracle_no_gradient_obc(const beom_params *P, oracle_state *S, int ilay) {
     }
 }
 
-/* ---- one time step: first_three_timesteps (:2151-2205) / gener_forward_backward
- *      (:2259-2290), rgld = 0, no_gradient_obc excluded (mcbc >= 0.5) ------------- */
+/* ---- rigid lid (rgld = 1), the fork's addition ------------------------------------------------ */
+/* epilogue of update_h, private_mod.f95:1648-1700: the two upper layers absorb the column's misfit.
+ * `real(x)` without a kind is DEFAULT real and so is the literal 0.5: the correction is rounded to
+ * real*4 before it is subtracted; the sum is taken again after layer 1 has changed. */
+void oracle_rgld_h_epilogue(const beom_params *P, oracle_state *S) {
+    const int l2 = P->nlay < 2 ? P->nlay : 2;            /* (hlay(ipnt, 2); oracle patch P2 for nlay = 1) */
+    for (int ipnt = 1; ipnt <= P->ndeg; ++ipnt) {
+        for (int pass = 1; pass <= 2; ++pass) {
+            double s = L2(S->hlay, ipnt, 1);
+            for (int i = 2; i <= P->nlay; ++i) s = s + L2(S->hlay, ipnt, i);
+            const float corr = 0.5f * (float)(s - S->h_th[ipnt]);
+            const int il = pass == 1 ? 1 : l2;
+            L2(S->hlay, ipnt, il) = L2(S->hlay, ipnt, il) - (double)corr;
+        }
+    }
+}
+
+/* h_u, h_v from the 3rd-order upstream-biased form with the 2-D d2hx, d2hy as the LAST Montgomery
+ * sweep left them (private_mod.f95:2237-2257, 2292-2314: all layers use the last layer's curvature) */
+void oracle_rgld_upstream_fluxes(const beom_params *P, oracle_state *S) {
+    for (int ilay = 1; ilay <= P->nlay; ++ilay)
+        for (int ipnt = 1; ipnt <= P->ndeg; ++ipnt) {
+            const int c5 = NEIG(5, ipnt), c7 = NEIG(7, ipnt);
+            double mask = S->mk_u[ipnt];
+            double hcen = (L2(S->hlay, c5, ilay) + L2(S->hlay, ipnt, ilay)) / (1.0 + mask);
+            const double uu = L2(S->u, ipnt, ilay);
+            L2(S->h_u, ipnt, ilay) = 0.5 * (uu + fabs(uu)) * (hcen - 0.16667 * S->d2hx[c5])
+                                   + 0.5 * (uu - fabs(uu)) * (hcen - 0.16667 * S->d2hx[ipnt]);
+            mask = S->mk_v[ipnt];
+            hcen = (L2(S->hlay, c7, ilay) + L2(S->hlay, ipnt, ilay)) / (1.0 + mask);
+            const double vv = L2(S->v, ipnt, ilay);
+            L2(S->h_v, ipnt, ilay) = 0.5 * (vv + fabs(vv)) * (hcen - 0.16667 * S->d2hy[c7])
+                                   + 0.5 * (vv - fabs(vv)) * (hcen - 0.16667 * S->d2hy[ipnt]);
+        }
+}
+
+/* surf_pressure, private_mod.f95:1705-1838: Poisson equation for the lid pressure by Gauss-Seidel
+ * sweeps in packed order (rp = 1), then the velocity correction */
+void oracle_surf_pressure(const beom_params *P, oracle_state *S) {
+    const int nd = P->ndeg, lm = P->lm, mm = P->mm;
+    const size_t n1 = N1;
+    double *rhs = (double *)calloc(n1, sizeof(double)), *prev = (double *)calloc(n1, sizeof(double));
+    const double rp = 1.000, pi_tol = 1.e-5, dl = P->dl, dt = P->dt;
+    const int maxiters = 1000;
+    for (int ilay = P->nlay; ilay >= 1; --ilay) {
+        for (int ipnt = 1; ipnt <= nd; ++ipnt)
+            if (S->subc[ipnt] > 1) {                                                     /* :1727-1736 */
+                const int c5 = NEIG(5, ipnt);
+                rhs[ipnt] = rhs[ipnt] - L2(S->h_u, ipnt, ilay) / (dl * dt);
+                rhs[c5] = rhs[c5] + L2(S->h_u, ipnt, ilay) / (dl * dt);
+            }
+        for (int ipnt = 1; ipnt <= nd; ++ipnt)
+            if (S->subc[ipnt + n1] > 1) {                                                /* :1740-1752 */
+                const int c7 = NEIG(7, ipnt);
+                rhs[ipnt] = rhs[ipnt] - L2(S->h_v, ipnt, ilay) / (dl * dt);
+                rhs[c7] = rhs[c7] + L2(S->h_v, ipnt, ilay) / (dl * dt);
+            }
+    }
+    double maxdiff = pi_tol + 1;
+    int iters = 0;
+    while (maxdiff > pi_tol && iters < maxiters) {                                       /* :1759-1802 */
+        maxdiff = 0;
+        for (int ipnt = 1; ipnt <= nd; ++ipnt) {
+            const int i = S->subc[ipnt], j = S->subc[ipnt + n1];
+            prev[ipnt] = S->pi_s[ipnt];
+            double x = (1 - rp) * S->pi_s[ipnt] - rp * S->Osum_[ipnt] * rhs[ipnt];
+            if (i < lm) { const int c1 = NEIG(1, ipnt); x = x + rp * S->Osum_[ipnt] * S->Ow[c1] * S->pi_s[c1]; }
+            if (j < mm) { const int c3 = NEIG(3, ipnt); x = x + rp * S->Osum_[ipnt] * S->Os[c3] * S->pi_s[c3]; }
+            if (i > 1) { const int c5 = NEIG(5, ipnt); x = x + rp * S->Osum_[ipnt] * S->Ow[ipnt] * S->pi_s[c5]; }
+            if (j > 1) { const int c7 = NEIG(7, ipnt); x = x + rp * S->Osum_[ipnt] * S->Os[ipnt] * S->pi_s[c7]; }
+            S->pi_s[ipnt] = x;
+        }
+        for (int ipnt = 1; ipnt <= nd; ++ipnt) {
+            const double diff = fabs(S->pi_s[ipnt] - prev[ipnt]);
+            if (diff > maxdiff) maxdiff = diff;
+        }
+        iters = iters + 1;
+    }
+    for (int ilay = 1; ilay <= P->nlay; ++ilay)                                          /* :1806-1819 */
+        for (int ipnt = 1; ipnt <= nd; ++ipnt)
+            if (S->subc[ipnt] > 1 && S->subc[ipnt] < lm + 1) {
+                const int c5 = NEIG(5, ipnt);
+                L2(S->u, ipnt, ilay) = L2(S->u, ipnt, ilay) - dt / dl * S->pi_s[ipnt];
+                L2(S->u, ipnt, ilay) = L2(S->u, ipnt, ilay) + dt / dl * S->pi_s[c5];
+            }
+    for (int ilay = 1; ilay <= P->nlay; ++ilay)                                          /* :1823-1833 */
+        for (int ipnt = 1; ipnt <= nd; ++ipnt)
+            if (S->subc[ipnt + n1] > 1 && S->subc[ipnt + n1] < mm + 1) {
+                const int c7 = NEIG(7, ipnt);
+                L2(S->v, ipnt, ilay) = L2(S->v, ipnt, ilay) - dt / dl * S->pi_s[ipnt];
+                L2(S->v, ipnt, ilay) = L2(S->v, ipnt, ilay) + dt / dl * S->pi_s[c7];
+            }
+    free(rhs); free(prev);
+}
+
+/* ---- one time step: first_three_timesteps (:2151-2223) / gener_forward_backward
+ *      (:2225-2316) ------------------------------------------------------------- */
 static void oracle_one_step(const beom_params *P, oracle_state *S, int tstp, int first3,
                             int upst, double gene, double ramp, double ctim) {
+    const int rgld = P->rgld > 0.5;
     if (first3) oracle_rebuild_fluxes(P, S);
+    else if (rgld) oracle_rgld_upstream_fluxes(P, S);                        /* :2237-2257 */
     oracle_update_h(P, S, gene, ramp, ctim);
+    if (rgld) oracle_rgld_h_epilogue(P, S);                                  /* :1648-1700 */
     for (int ilay = 1; ilay <= P->nlay; ++ilay) {
         oracle_update_mont(P, S, ilay);
         if (first3 || (P->dvis > 1.e-3 && upst) || P->svis > 0)              /* :2188,2268 */
@@ -524,12 +626,17 @@ static void oracle_one_step(const beom_params *P, oracle_state *S, int tstp, int
         if (P->flag_nudging && P->mcbc < 0.5 && S->segm)                    /* :2201-2204,2285-2288 */
             oracle_no_gradient_obc(P, S, ilay);
     }
+    if (rgld) {                                                              /* :2207-2221, 2292-2314 */
+        if (first3) oracle_rebuild_fluxes(P, S);
+        else oracle_rgld_upstream_fluxes(P, S);
+        oracle_surf_pressure(P, S);
+    }
 }
 
 /* ---- integrate_time, private_mod.f95:1853-1912, for steps tstp_first.. ---------- */
 int oracle_step(const beom_params *P, oracle_state *S, int tstp_first, int nsteps,
                 double tres, double dtd8, double dt_r, double rsta, int n_3d) {
-    if (P->rgld > 0.5) return -1;
+    if (P->rgld > 0.5 && !(S->pi_s && S->Ow && S->Os && S->Osum_)) return -1;
     if (P->svis > 0 && !S->uu4) return -1;
     if (P->flag_nudging && P->mcbc < 0.5 && !S->segm) return -2;
     for (int tstp = tstp_first; tstp < tstp_first + nsteps; ++tstp) {
@@ -551,7 +658,7 @@ int oracle_step(const beom_params *P, oracle_state *S, int tstp_first, int nstep
             const double c1 = tres + dtd8 * 1.0;
             if (rsta < 0.5 && c1 < dt_r) ramp = c1 / dt_r;
         }
-        const double gene = first3 ? 0.0 : P->g_fb;                          /* :1859,1877 */
+        const double gene = (first3 || P->rgld > 0.5) ? 0.0 : P->g_fb;       /* :1859,1877; :1880-1884: no multistep with a lid */
         oracle_one_step(P, S, tstp, first3, upst, gene, ramp, ctim);
     }
     return 0;

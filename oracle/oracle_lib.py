@@ -24,7 +24,8 @@ class OracleState(C.Structure):
     _fields_ = ([(k, C.c_void_p) for k in _STATIC] + [(k, C.c_void_p) for k in STATE_NAMES]
                 + [(k, C.c_void_p) for k in SCRATCH_NAMES] + [(k, C.c_void_p) for k in _SCR_L]
                 + [("segm", C.c_void_p), ("nseg", C.c_int64)]
-                + [(k, C.c_void_p) for k in ("delu", "delv", "uu4", "vv4")])
+                + [(k, C.c_void_p) for k in ("delu", "delv", "uu4", "vv4")]
+                + [(k, C.c_void_p) for k in ("pi_s", "Ow", "Os", "Osum_")])
 
 
 def build():
@@ -70,6 +71,8 @@ def load():
         _lib.oracle_rebuild_fluxes.argtypes = [PP, SP]
         _lib.oracle_distribute_stress.argtypes = [PP, SP]
         _lib.oracle_no_gradient_obc.argtypes = [PP, SP, ci]
+        for nm in ("oracle_rgld_h_epilogue", "oracle_rgld_upstream_fluxes", "oracle_surf_pressure"):
+            getattr(_lib, nm).argtypes = [PP, SP]
         _lib.oracle_step.argtypes = [PP, SP, ci, ci, cd, cd, cd, cd, ci]
         _lib.oracle_step.restype = ci
         assert _lib.oracle_sizeof_params() == C.sizeof(BeomParams)
@@ -97,7 +100,7 @@ class Oracle:
         self.st = OracleState()
         self.segm = np.ascontiguousarray(f.segm, dtype=np.int32) if getattr(f, "segm", None) is not None else None
         for k, _ in OracleState._fields_:
-            if k in ("segm", "nseg", "delu", "delv", "uu4", "vv4"):
+            if k in ("segm", "nseg", "delu", "delv", "uu4", "vv4", "pi_s", "Ow", "Os", "Osum_"):
                 continue
             arr = self.a[k]
             present = arr is not None and (k not in ("hdot", "tide", "bodf") or f.has.get(k, True))
@@ -106,6 +109,12 @@ class Oracle:
         self.biharm = {k: np.zeros((f.p.nlay, n1)) for k in ("delu", "delv", "uu4", "vv4")}
         for k, a in self.biharm.items():
             setattr(self.st, k, a.ctypes.data)
+        self.rgld = {}
+        if getattr(f, "pi_s", None) is not None:                     # rigid lid (rgld = 1)
+            self.rgld = {"pi_s": np.array(f.pi_s, dtype=np.float64, copy=True),
+                         "Ow": np.ascontiguousarray(f.Ow), "Os": np.ascontiguousarray(f.Os), "Osum_": np.ascontiguousarray(f.Osum_)}
+            for k, a in self.rgld.items():
+                setattr(self.st, k, a.ctypes.data)
         self.st.segm = self.segm.ctypes.data if self.segm is not None else None
         self.st.nseg = self.segm.shape[1] if self.segm is not None else 0
 
@@ -123,6 +132,9 @@ class Oracle:
     def update_v(self, ilay, gene, ramp, ctim): self.lib.oracle_update_v(C.byref(self.prm), C.byref(self.st), ilay, gene, ramp, ctim)
     def no_gradient_obc(self, ilay): self.lib.oracle_no_gradient_obc(C.byref(self.prm), C.byref(self.st), ilay)
     def rebuild_fluxes(self): self.lib.oracle_rebuild_fluxes(C.byref(self.prm), C.byref(self.st))
+    def rgld_h_epilogue(self): self.lib.oracle_rgld_h_epilogue(C.byref(self.prm), C.byref(self.st))
+    def rgld_upstream_fluxes(self): self.lib.oracle_rgld_upstream_fluxes(C.byref(self.prm), C.byref(self.st))
+    def surf_pressure(self): self.lib.oracle_surf_pressure(C.byref(self.prm), C.byref(self.st))
     def distribute_stress(self): self.lib.oracle_distribute_stress(C.byref(self.prm), C.byref(self.st))
 
     def state(self) -> dict:

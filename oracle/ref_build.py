@@ -73,6 +73,7 @@ subroutine oracle_dump_static()
   write( unum ) nudg, fnud, hdot, tide, w_ti, bodf, taus
   write( unum ) real(invf, 8), real(dt, 8)
   write( unum ) hlay, u, v
+  if ( rgld > 0.5_rw ) write( unum ) pi_s, Ow, Os, Osum_
   close( unum )
 end subroutine oracle_dump_static
 
@@ -102,6 +103,7 @@ subroutine oracle_dump( tstp )
     write( unum ) tt3d, tb3d, tu3d
     write( unum ) real(ctim, 8), real(ramp, 8), real(gene, 8)
     if ( svis > 0._rw ) write( unum ) delu, delv, UU4, VV4
+    if ( rgld > 0.5_rw ) write( unum ) pi_s
     close( unum )
   end if
 end subroutine oracle_dump

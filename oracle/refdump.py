@@ -42,6 +42,9 @@ def read_static(path):
     d["invf"], d["dt"] = (float(x) for x in r.take("<f8", (2,)))
     for k in ("hlay", "u", "v"):
         d[k] = r.take("<f8", (nlay, n1))
+    if r.pos < r.buf.size:                    # rgld = 1: lid pressure and its operators
+        for k in ("pi_s", "Ow", "Os", "Osum_"):
+            d[k] = r.take("<f8", (n1,))
     r.done()
     return d
 
@@ -66,8 +69,11 @@ def read_step(path, nlay, ndeg):
     for k in ("tt3d", "tb3d", "tu3d"):
         d[k] = r.take("<f8", (nlay, 2, n1))
     d["ctim"], d["ramp"], d["gene"] = (float(x) for x in r.take("<f8", (3,)))
-    if r.pos < r.buf.size:                    # svis > 0: biharmonic work arrays
+    left = (r.buf.size - r.pos) // 8
+    if left >= 4 * nlay * n1:                 # svis > 0: biharmonic work arrays
         for k in ("delu", "delv", "uu4", "vv4"):
             d[k] = r.take("<f8", (nlay, n1))
+    if r.pos < r.buf.size:                    # rgld = 1: the lid pressure
+        d["pi_s"] = r.take("<f8", (n1,))
     r.done()
     return d

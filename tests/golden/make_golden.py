@@ -262,6 +262,12 @@ CASES = {
     "tc_outcrop_seamount_3d_3l": (lambda: _short(I.case_outcrop_seamount(lx=100.0e3, nlay=3, three_d=True)), "private_mod.f95"),
     "topdrag_topo_2l": (case_topdrag, "private_mod.f95"),
     "topdrag_sill_ocrp_2l": (case_topdrag_ocrp, "private_mod.f95"),
+    # the fork's rigid lid (rgld = 1: Poisson equation for the lid pressure by Gauss-Seidel sweeps, :1705-1838; needs
+    # ocrp = 1, since the operators are set up inside get_equilibrium_thickness_h_0, :505-563; g_fb = 1 is overridden, :1880)
+    "rigid_lid_sill_2l": (lambda: (lambda pf: (pf[0].replace(rgld="1."), pf[1]))(
+        I.case_sill_exchange3d(lm=24, mm=31, nlay=2, dt_s=0.01, npts=5, sill_halfwidth=6.0)), "private_mod.f95"),
+    "rigid_lid_closed_3l_wind": (lambda: (lambda pf: (pf[0].replace(rgld="1.", ocrp="1.", bdrg="2.e-4", tauw=["0.05", "0.02"], g_fb="0."), pf[1]))(
+        _short(I.case_conservation(lx=200.0e3, nlay=3, outc=1, xper=0, yper=0))), "private_mod.f95"),
 }
 
 

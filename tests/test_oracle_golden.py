@@ -23,6 +23,9 @@ def test_init_mirror_matches_reference_static_state(name):
     for k in ("neig", "subc", "mk_u", "mk_v", "mk_n", "mkpe", "mkpi", "h_th", "nudg", "fnud",
               "hdot", "tide", "w_ti", "bodf", "taus", "hlay", "u", "v"):
         assert same(getattr(f, k), g.static(k)), k
+    if float(g.p.rgld) > 0.5:                  # rigid lid: start pressure and Poisson operators (:505-563)
+        for k in ("pi_s", "Ow", "Os", "Osum_"):
+            assert same(getattr(f, k), g.static(k)), k
     # fcor(0) is a real*4 SUM whose order is the compiler's (private_mod.f95:933): tolerance
     assert same(f.fcor[1:], g.static("fcor")[1:])
     assert abs(f.fcor[0] - g.static("fcor")[0]) <= 1e-5 * max(abs(g.static("fcor")).max(), 1e-30)
@@ -51,6 +54,8 @@ def test_oracle_step_matches_reference_bitwise(name):
             assert same_bits(st[k], g.step(tgt, k)), (name, tgt, k)
         for k in SCRATCH:
             assert same_bits(o.a[k], g.step(tgt, k)), (name, tgt, k)
+        if float(g.p.rgld) > 0.5:
+            assert same_bits(o.rgld["pi_s"], g.step(tgt, "pi_s")), (name, tgt, "pi_s")
 
 
 @pytest.mark.parametrize("name", NAMES)
@@ -71,13 +76,18 @@ def test_oracle_sweeps_compose_to_step(name):
         c = float(p.dtd8) * (1 if first3 else tstp)
         if float(p.rsta) < 0.5 and c < float(p.dt_r):
             ramp = c / float(p.dt_r)
-        gene = 0.0 if first3 else float(p.g_fb)
+        rgld = float(p.rgld) > 0.5
+        gene = 0.0 if (first3 or rgld) else float(p.g_fb)
         upst = tstp == 1 or (not first3 and tstp % p.n_3d == 0)
         if upst:
             b.distribute_stress()
         if first3:
             b.rebuild_fluxes()
+        elif rgld:
+            b.rgld_upstream_fluxes()
         b.update_h(gene, ramp, ctim)
+        if rgld:
+            b.rgld_h_epilogue()
         for il in range(1, p.nlay + 1):
             b.update_mont(il)
             if first3 or (float(p.dvis) > 1e-3 and upst):
@@ -87,5 +97,8 @@ def test_oracle_sweeps_compose_to_step(name):
                 getattr(b, "update_" + w)(il, gene, ramp, ctim)
             if f.flag_nudging and float(p.mcbc) < 0.5:
                 b.no_gradient_obc(il)
+        if rgld:
+            b.rebuild_fluxes() if first3 else b.rgld_upstream_fluxes()
+            b.surf_pressure()
     for k in STATE:
         assert same(a.state()[k], b.state()[k]), k
