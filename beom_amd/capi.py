@@ -133,6 +133,8 @@ def load(path: Optional[str] = None) -> C.CDLL:
     lib.beom_device_pci_bus_id.restype = ci
     lib.beom_create.argtypes = [C.POINTER(BeomParams), ci, ipp, ipp] + [dpp] * 14 + [C.POINTER(H), cp, ci]
     lib.beom_destroy.argtypes = [H]
+    lib.beom_set_rigid_lid.argtypes = [H, dpp, dpp, dpp, dpp, cp, ci]
+    lib.beom_download_pressure.argtypes = [H, dpp, cp, ci]
     lib.beom_upload_state.argtypes = [H] + [dpp] * 13 + [cp, ci]
     lib.beom_download_state.argtypes = [H] + [dpp] * 13 + [cp, ci]
     lib.beom_download_scratch.argtypes = [H] + [dpp] * 6 + [cp, ci]
@@ -208,7 +210,7 @@ def load(path: Optional[str] = None) -> C.CDLL:
     return lib
 
 
-EXPORTS = ("beom_abi_version", "beom_device_count", "beom_device_pci_bus_id", "beom_graph_stats", "beom_download_diag", "beom_create", "beom_destroy",
+EXPORTS = ("beom_abi_version", "beom_device_count", "beom_device_pci_bus_id", "beom_graph_stats", "beom_download_diag", "beom_create", "beom_destroy", "beom_set_rigid_lid", "beom_download_pressure",
            "beom_upload_state", "beom_download_state", "beom_download_scratch", "beom_step",
            "beom_sync", "beom_update_h", "beom_update_mont_rvor_pvor_dive_kine",
            "beom_update_viscosity", "beom_update_u", "beom_update_v", "beom_rebuild_fluxes",
@@ -255,8 +257,21 @@ class Engine:
         if f.flag_nudging and float(f.p.mcbc) < 0.5 and f.segm is not None:     # no_gradient_obc (:2613)
             seg = np.ascontiguousarray(f.segm, dtype=np.int32)
             self._check(self.lib.beom_set_open_boundaries(self.h, seg.shape[1], _ip(seg), self._err, ERRLEN))
+        if float(f.p.rgld) > 0.5:                                                # rigid lid: the Poisson operators (:505-563)
+            self._check(self.lib.beom_set_rigid_lid(self.h, _dp(f.Ow), _dp(f.Os), _dp(f.Osum_), _dp(f.pi_s),
+                                                    self._err, ERRLEN))
         if upload:
             self.upload(**{k: getattr(f, k) for k in STATE_NAMES})
+
+    def upload_pressure(self, pi_s):
+        """The lid pressure pi_s(0:ndeg) of a rigid-lid handle (rgld = 1)."""
+        self._check(self.lib.beom_set_rigid_lid(self.h, None, None, None, _dp(np.ascontiguousarray(pi_s, dtype=np.float64)),
+                                                self._err, ERRLEN))
+
+    def download_pressure(self):
+        out = np.zeros(self.p.ndeg + 1)
+        self._check(self.lib.beom_download_pressure(self.h, _dp(out), self._err, ERRLEN))
+        return out
 
     def _check(self, rc):
         if rc != 0:

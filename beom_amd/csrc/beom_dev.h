@@ -67,6 +67,12 @@ struct DevView {
     const int32_t *segm; int nseg;
     // stress work arrays
     double *layt, *layb, *layu, *taub, *taum;
+    // rigid lid (rgld = 1, private_mod.f95:505-563, 1705-1838): lid pressure, Poisson operators, right-hand side, previous
+    // iterate; the packed cells in Gauss-Seidel wavefront order (anti-diagonals i + j: what the serial sweep computes)
+    double *pi_s, *pi_rhs, *pi_prev;
+    const double *Ow, *Os, *Osum_;
+    const int32_t *sor_order, *sor_dstart;
+    int sor_ndiag;
     // constants by value
     double dl, dt, grav, rho0, beta, epsi, gamm, del1, del2, hmin, hsal, bvis, dvis, bdrg, tdrg,
         qdrg, hsbl, hbbl, uadv, ocrp, rgld, invf, w_ti;

@@ -82,6 +82,9 @@ struct beom_engine {
     int use_graph = 0;                 // option "graph": 0 = never (default: measured no gain), 1 = whenever the step allows,
                                        // -1 = automatic (dense frames of at most 4 M cell-layers)
     long long graph_steps = 0, eager_steps = 0;
+    // rigid lid (rgld = 1): the caller's subc and the packed -> device index map, kept for beom_set_rigid_lid
+    std::vector<int32_t> subc_host, dev_index;
+    bool lid = false, lid_ready = false;
     char last_err[512] = {0};
 };
 static void graphs_clear(beom_engine *E) {
@@ -186,7 +189,12 @@ int beom_create(const beom_params *prm, int device, const int32_t *neig, const i
     if (!prm || !out) { set_err(errm, errm_len, "beom_create: null argument"); return -1; }
     if (prm->abi_version != BEOM_ABI_VERSION) { set_err(errm, errm_len, "beom_create: ABI version mismatch (%d vs %d)", prm->abi_version, BEOM_ABI_VERSION); return -2; }
     if (prm->nlay < 1 || prm->nlay > BEOM_MAX_LAYERS || prm->ndeg < 1 || prm->lm < 1 || prm->mm < 1) { set_err(errm, errm_len, "beom_create: bad sizes"); return -3; }
-    if (prm->rgld > 0.5) { set_err(errm, errm_len, "beom_create: rgld = 1 (rigid lid, private_mod.f95:1705-1838) is not implemented on the GPU path"); return -5; }
+    if (prm->rgld > 0.5 && (prm->variant == 1 || prm->slab_mm > 0 || prm->ocrp < 0.5)) {
+        // (private_mod3d.f95 has no lid; the Poisson operators are only initialised with ocrp = 1, :505-563; the pressure sweep
+        // couples the whole frame, so no bands)
+        set_err(errm, errm_len, "beom_create: rgld = 1 (rigid lid, private_mod.f95:1705-1838) needs variant 0, ocrp = 1 and a whole frame (no bands)");
+        return -5;
+    }
     if (prm->variant == 1 && prm->nlay < 3) { set_err(errm, errm_len, "beom_create: variant 1 (private_mod3d.f95) needs nlay >= 3"); return -7; }
     if (!neig || !subc || !mk_u || !mk_v || !mk_n || !mkpe || !mkpi || !fcor || !h_th || !nudg || !fnud) { set_err(errm, errm_len, "beom_create: null static array"); return -1; }
     int ndev = 0;
@@ -306,6 +314,14 @@ int beom_create(const beom_params *prm, int device, const int32_t *neig, const i
         }
     }
     d.embedded = E->embedded ? 1 : 0;
+    E->lid = prm->rgld > 0.5;
+    if (E->lid) {
+        E->subc_host.assign(subc, subc + 2 * n1h);
+        E->dev_index.assign(n1h, 0);
+        const int P = (d.L + 15) / 16 * 16;
+        for (size_t p = 1; p < n1h; ++p)
+            E->dev_index[p] = E->embedded ? slot_of[p] : E->dense ? (int32_t)((p - 1) % d.L + 1 + ((p - 1) / d.L) * (size_t)P) : (int32_t)p;
+    }
     // device layout: padded row pitch for dense frames (DevView::P), the caller's packed layout otherwise
     d.P = 0; d.ncell = prm->ndeg;
     if (E->dense) {
@@ -385,6 +401,7 @@ int beom_create(const beom_params *prm, int device, const int32_t *neig, const i
     E->fuse = getenv("BEOM_NO_FUSE") == nullptr;
     E->fuse_uv = getenv("BEOM_NO_FUSE") == nullptr && getenv("BEOM_NO_FUSE_UV") == nullptr;
     E->fuse_muv = getenv("BEOM_MUV") != nullptr;
+    if (E->lid) E->fuse = E->fuse_uv = E->fuse_muv = false;      // the lid's flux rebuild reads the stored d2hx, d2hy of the last layer
     d.edge_global = getenv("BEOM_EDGE_GLOBAL") != nullptr;
     E->wind = false;
     if (taus) for (size_t i = 0; i < 2 * n1h; ++i) if (std::fabs(taus[i]) > 1.e-7) { E->wind = true; break; }   // :1945
@@ -406,6 +423,7 @@ int beom_create(const beom_params *prm, int device, const int32_t *neig, const i
     AL(pcd, nl * n1) AL(qlr, nl * n1)
     AL(mont, nl * n1) AL(rvor, nl * n1) AL(pvor, nl * n1) AL(dive, nl * n1) AL(d2hx, nl * n1) AL(d2hy, nl * n1)
     if (prm->svis > 0.0) { AL(delu, nl * n1) AL(delv, nl * n1) AL(uu4, nl * n1) AL(vv4, nl * n1) }
+    if (E->lid) { AL(pi_s, n1) AL(pi_rhs, n1) AL(pi_prev, n1) }
     if (E->wind) AL(layt, nl * n1)
     if (E->bot) { AL(layb, nl * n1) AL(taub, 2 * n1) }
     if (E->top) { AL(layu, nl * n1) AL(taum, 2 * n1) }
@@ -561,6 +579,57 @@ int beom_download_scratch(beom_handle E, double *mont, double *rvor, double *pvo
     return 0;
 }
 
+int beom_set_rigid_lid(beom_handle E, const double *Ow, const double *Os, const double *Osum_, const double *pi_s,
+                       char *errm, int errm_len) {
+    if (!E) { set_err(errm, errm_len, "null handle"); return -1; }
+    if (!E->lid) { set_err(errm, errm_len, "beom_set_rigid_lid: the handle was created with rgld = 0"); return -5; }
+    HIP_TRY(hipSetDevice(E->device));
+    DevView &d = E->d;
+    int rc;
+    if (!E->lid_ready) {
+        if (!Ow || !Os || !Osum_) { set_err(errm, errm_len, "beom_set_rigid_lid: the operators Ow, Os, Osum_ are needed on the first call"); return -1; }
+        if ((rc = dev_upload(E, &d.Ow, Ow, 1, 1, errm, errm_len))) return rc;
+        if ((rc = dev_upload(E, &d.Os, Os, 1, 1, errm, errm_len))) return rc;
+        if ((rc = dev_upload(E, &d.Osum_, Osum_, 1, 1, errm, errm_len))) return rc;
+        // the packed cells by anti-diagonal i + j, packed order within one (any order would do there)
+        const size_t n1h = (size_t)d.ndeg + 1;
+        const int ndiag = d.L + d.M + 1;                              // keys i + j in 0..L+M
+        std::vector<int32_t> start((size_t)ndiag + 1, 0), order(n1h > 1 ? n1h - 1 : 1, 0);
+        for (size_t p = 1; p < n1h; ++p) {
+            const int key = E->subc_host[p] + E->subc_host[p + n1h];
+            if (key < 0 || key >= ndiag) { set_err(errm, errm_len, "beom_set_rigid_lid: subc outside the frame"); return -3; }
+            ++start[(size_t)key + 1];
+        }
+        for (int k = 0; k < ndiag; ++k) start[(size_t)k + 1] += start[k];
+        std::vector<int32_t> fill(start.begin(), start.end() - 1);
+        for (size_t p = 1; p < n1h; ++p) order[(size_t)fill[E->subc_host[p] + E->subc_host[p + n1h]]++] = E->dev_index[p];
+        int32_t *q = nullptr;
+        if ((rc = dev_alloc(E, &q, order.size(), errm, errm_len, false))) return rc;
+        HIP_TRY(hipMemcpyAsync(q, order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice, E->stream));
+        d.sor_order = q;
+        if ((rc = dev_alloc(E, &q, start.size(), errm, errm_len, false))) return rc;
+        HIP_TRY(hipMemcpyAsync(q, start.data(), start.size() * sizeof(int32_t), hipMemcpyHostToDevice, E->stream));
+        d.sor_dstart = q;
+        d.sor_ndiag = ndiag;
+        HIP_TRY(hipStreamSynchronize(E->stream));       // (order, start are host temporaries)
+        E->lid_ready = true;
+    }
+    if (pi_s && (rc = slice_to_device<double>(E, d.pi_s, pi_s, 1, 1, 0, errm, errm_len))) return rc;
+    HIP_TRY(hipStreamSynchronize(E->stream));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int beom_download_pressure(beom_handle E, double *pi_s, char *errm, int errm_len) {
+    if (!E) { set_err(errm, errm_len, "null handle"); return -1; }
+    if (!E->lid) { set_err(errm, errm_len, "beom_download_pressure: the handle was created with rgld = 0"); return -5; }
+    HIP_TRY(hipSetDevice(E->device));
+    const int rc = copy_out(E, pi_s, E->d.pi_s, 1, errm, errm_len);
+    if (rc) return rc;
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int beom_sync(beom_handle E, char *errm, int errm_len) {
     if (!E) { set_err(errm, errm_len, "null handle"); return -1; }
     HIP_TRY(hipSetDevice(E->device));
@@ -698,6 +767,22 @@ static bool can_fuse(const beom_engine *E, int n_3d, bool first3) {
     if (E->P.dvis > 1.e-3) return true;           // refresh steps: Leith in the sweep; others: standing v_cc, v_ll
     return !first3;                               // steps 1-3 call update_viscosity unconditionally (:2188)
 }
+// rigid lid: rebuild the transports from the new h and velocities (steps 1-3: centred, :2166-2177; later: upstream with the
+// curvatures of the last layer, :2237-2257), then the pressure solve and the velocity correction (surf_pressure, :1705-1838)
+static void launch_lid_fluxes(beom_engine *E, bool first3) {
+    if (first3) { launch_rebuild(E); return; }
+    const dim3 g((unsigned)((E->d.ncell + BEOM_BLOCK - 1) / BEOM_BLOCK), (unsigned)E->d.nlay, 1);
+    hipLaunchKernelGGL(k_rgld_upstream_fluxes, g, dim3(BEOM_BLOCK), 0, E->stream, E->d);
+}
+static void launch_lid_h_epilogue(beom_engine *E) {
+    hipLaunchKernelGGL(k_rgld_h_epilogue, dim3((unsigned)((E->d.ncell + BEOM_BLOCK - 1) / BEOM_BLOCK)), dim3(BEOM_BLOCK), 0, E->stream, E->d);
+}
+static void launch_lid_pressure(beom_engine *E) {
+    const dim3 g1((unsigned)((E->d.ncell + BEOM_BLOCK - 1) / BEOM_BLOCK)), g((unsigned)((E->d.ncell + BEOM_BLOCK - 1) / BEOM_BLOCK), (unsigned)E->d.nlay, 1);
+    hipLaunchKernelGGL(k_rgld_rhs, g1, dim3(BEOM_BLOCK), 0, E->stream, E->d);
+    hipLaunchKernelGGL(k_rgld_sor, dim3(1), dim3(SOR_THREADS), 0, E->stream, E->d);
+    hipLaunchKernelGGL(k_rgld_correct, g, dim3(BEOM_BLOCK), 0, E->stream, E->d);
+}
 static void launch_stress(beom_engine *E) {
     if (!(E->wind || E->bot || E->top)) return;
     const int w = E->wind, b = E->bot, t = E->top;
@@ -743,7 +828,7 @@ static StepScalars step_scalars(const beom_engine *E, int tstp, double tres, dou
         s.upst = (tstp % n_3d) == 0;                               // :1889-1892
         s.stress = s.upst;                                         // :1894-1896
     }
-    s.gene = s.first3 ? 0.0 : E->P.g_fb;                           // :1859,1877
+    s.gene = (s.first3 || (E->lid && E->P.g_fb > 0.5)) ? 0.0 : E->P.g_fb;      // :1859,1877; :1880-1884: no multistep with a lid
     s.n_3d = n_3d;
     s.fused = can_fuse(E, n_3d, s.first3);
     s.fused_uv = E->dense && E->fuse_uv && !(E->P.svis > 0.0);
@@ -758,9 +843,11 @@ static void one_step(beom_engine *E, int tstp, const StepScalars &s) {
     StepTimer *T = E->timer;
     if (T) T->st = E->stream;
     if (s.stress) launch_stress(E);
-    if (s.first3) launch_rebuild(E);                               // :2166-2177
+    if (E->lid) launch_lid_fluxes(E, s.first3);
+    else if (s.first3) launch_rebuild(E);                          // :2166-2177
     if (T) T->begin(0);
     launch_h(E, s.gene, s.ramp, s.ctim);                           // :2181,2259
+    if (E->lid) launch_lid_h_epilogue(E);                          // :1648-1700
     const bool leith = E->P.dvis > 1.e-3 && s.upst;
     const bool u_first = tstp % 2 == 0;                            // :2193-2199,2276-2282
     if (s.muv) {                                                   // :2187-2199, 2266-2282 in one sweep
@@ -802,6 +889,7 @@ static void one_step(beom_engine *E, int tstp, const StepScalars &s) {
         hipLaunchKernelGGL(k_no_gradient_obc, g, dim3(BEOM_BLOCK), 0, E->stream, E->d, 0);
         hipLaunchKernelGGL(k_no_gradient_obc, g, dim3(BEOM_BLOCK), 0, E->stream, E->d, 1);
     }
+    if (E->lid) { launch_lid_fluxes(E, s.first3); launch_lid_pressure(E); }       // :2206-2222, 2290-2316
 }
 
 // ---- HIP graphs for launch-bound frames -------------------------------------------------------------
@@ -812,7 +900,7 @@ static std::vector<void *> pointer_key(const beom_engine *E) {
 }
 // a step whose launches do not depend on tstp except through its parity: steady forward-backward stepping
 static bool graph_step_ok(const beom_engine *E, int tstp, double tres, double dtd8, double dt_r, double rsta, int n_3d) {
-    if (E->use_graph == 0 || E->timer || tstp <= 3 || n_3d != 1 || E->d.has_tide || E->d.slab) return false;
+    if (E->use_graph == 0 || E->timer || tstp <= 3 || n_3d != 1 || E->d.has_tide || E->d.slab || E->lid) return false;
     if (E->use_graph < 0 && (E->d.ncell * E->d.nlay > 4000000ll || !E->dense)) return false;
     const double ctim = tres + dtd8 * (double)tstp;
     if (rsta < 0.5 && ctim < dt_r && E->d.has_stress) return false;      // the wind is still ramping up (:1898-1901)
@@ -856,6 +944,7 @@ int beom_step(beom_handle E, int tstp_first, int nsteps, double tres, double dtd
     if (!E) { set_err(errm, errm_len, "null handle"); return -1; }
     if (tstp_first < 1 || nsteps < 0 || n_3d < 1) { set_err(errm, errm_len, "beom_step: bad arguments"); return -3; }
     if (E->P.flag_nudging && E->P.mcbc < 0.5 && !E->obc) { set_err(errm, errm_len, "beom_step: mcbc = 0 with nudging needs beom_set_open_boundaries (no_gradient_obc, private_mod.f95:2613-2679)"); return -6; }
+    if (E->lid && !E->lid_ready) { set_err(errm, errm_len, "beom_step: rgld = 1 needs beom_set_rigid_lid (the Poisson operators Ow, Os, Osum_ and the lid pressure, private_mod.f95:505-563)"); return -6; }
     HIP_TRY(hipSetDevice(E->device));
     const int end = tstp_first + nsteps;
     int tstp = tstp_first;
@@ -1078,8 +1167,11 @@ int beom_download_diag(beom_handle E, float *pvor4, float *mont4, float *vcc4, c
     if (!E->diag4[0])
         for (int q = 0; q < 3; ++q) { HIP_TRY(hipMalloc((void **)&E->diag4[q], n * sizeof(float))); E->allocs.push_back(E->diag4[q]); }
     const dim3 g = E->grid_cells_layers_flat, b(BEOM_BLOCK);
-    if (vcc4) hipLaunchKernelGGL(k_diag_w12, g, b, 0, E->stream, d, d.d2hx, d.d2hy);
-    hipLaunchKernelGGL(k_diag_records, g, b, 0, E->stream, d, (const double *)d.d2hx, (const double *)d.d2hy,
+    // work arrays: scratch that is dead between steps — the curvatures, or with a lid (whose next step reads the stored
+    // curvatures of the last layer, :2237-2257) the product arrays of the fused sweeps, which a lid handle never runs
+    double *w1 = E->lid ? d.pcd : d.d2hx, *w2 = E->lid ? d.qlr : d.d2hy;
+    if (vcc4) hipLaunchKernelGGL(k_diag_w12, g, b, 0, E->stream, d, w1, w2);
+    hipLaunchKernelGGL(k_diag_records, g, b, 0, E->stream, d, (const double *)w1, (const double *)w2,
                        pvor4 ? E->diag4[0] : nullptr, mont4 ? E->diag4[1] : nullptr, vcc4 ? E->diag4[2] : nullptr);
     for (int q = 0; q < 3; ++q)
         if (dst[q]) HIP_TRY(hipMemcpyAsync(dst[q], E->diag4[q], n * sizeof(float), hipMemcpyDeviceToHost, E->stream));
@@ -1146,9 +1238,9 @@ int beom_set_option(beom_handle E, const char *name, int value) {
     if (!E || !name) return -1;
     graphs_clear(E);                   // launches baked into a graph may no longer be the ones this option selects
     if (!strcmp(name, "fuse")) { E->fuse = value != 0; E->fuse_uv = value != 0; }
-    else if (!strcmp(name, "fuse_mont_visc")) E->fuse = value != 0;
-    else if (!strcmp(name, "fuse_uv")) E->fuse_uv = value != 0;
-    else if (!strcmp(name, "fuse_muv")) E->fuse_muv = value != 0;
+    else if (!strcmp(name, "fuse_mont_visc")) E->fuse = value != 0 && !E->lid;      // (a lid handle keeps the separate sweeps)
+    else if (!strcmp(name, "fuse_uv")) E->fuse_uv = value != 0 && !E->lid;
+    else if (!strcmp(name, "fuse_muv")) E->fuse_muv = value != 0 && !E->lid;
     else if (!strcmp(name, "graph")) E->use_graph = value;
     else if (!strcmp(name, "keep_diag")) E->d.keep_diag = value != 0;
     else if (!strcmp(name, "lean_d2h")) E->lean_d2h = value != 0;

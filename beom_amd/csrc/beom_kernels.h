@@ -744,7 +744,7 @@ __device__ __forceinline__ double uv_core(const C &c, const DevView &d, int ilay
                       + 0.5 * (vold - fabs(vold)) * (hcen - 0.16667 * sh.template d2h_s<XDIR>());   // rgld = 0 (:1491,1577)
     if (STORE && do_store) {
         LL(io.vel_out, ipnt, ilay) = vold;
-        LL(io.hp_out, ipnt, ilay) = hnew;
+        if (d.rgld < 0.5) LL(io.hp_out, ipnt, ilay) = hnew;          // (:1491, :1577: with a lid the transports are rebuilt after the sweeps)
         if (copy_hist) {                       // single-layer entry points: shift like the reference
             const double m2 = LL(io.dm1, ipnt, ilay), m3 = LL(io.dm2, ipnt, ilay);
             LL(const_cast<double *>(io.dm0), ipnt, ilay) = m2;
@@ -1566,6 +1566,7 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_out_convert(DevView d, const flo
         const long long o = pk + nd * (k - 1);
         const double h = LL(d.hlay, ipnt, k) - (double)h0r4[o];
         acc = (k == d.nlay) ? (float)h : (float)(h + (double)acc);
+        if (d.rgld > 0.5 && k == 1) acc = (float)d.pi_s[ipnt];       // :2864-2872: the lid pressure in the top record
         if (eta) eta[o] = acc;
         if (u4) u4[o] = (float)LL(d.u, ipnt, k);
         if (v4) v4[o] = (float)LL(d.v, ipnt, k);
@@ -1686,6 +1687,117 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_no_gradient_obc(DevView d, int p
         }
     }
 #undef SEG
+}
+
+// ---- rigid lid (rgld = 1), the fork's addition: private_mod.f95:1648-1700, 1705-1838, 2237-2257, 2292-2314 ----------
+// (a fork-specific option outside every BASELINE configuration: table-driven kernels, one launch per piece)
+__global__ __launch_bounds__(BEOM_BLOCK) void k_rgld_h_epilogue(DevView d) {                 // :1648-1700
+    const int ipnt = blockIdx.x * BEOM_BLOCK + threadIdx.x + 1;
+    if (!cell_slot(d, ipnt)) return;
+    const int l2 = d.nlay < 2 ? d.nlay : 2;
+    for (int pass = 1; pass <= 2; ++pass) {
+        double s = LL(d.hlay, ipnt, 1);
+        for (int i = 2; i <= d.nlay; ++i) s = s + LL(d.hlay, ipnt, i);
+        const float corr = 0.5f * (float)(s - d.h_th[ipnt]);       // `0.5*real(...)`: DEFAULT real, rounded before the subtraction
+        const int il = pass == 1 ? 1 : l2;
+        LL(d.hlay, ipnt, il) = LL(d.hlay, ipnt, il) - (double)corr;
+    }
+}
+__global__ __launch_bounds__(BEOM_BLOCK) void k_rgld_upstream_fluxes(DevView d) {            // :2237-2257, 2292-2314
+    const int ipnt = blockIdx.x * BEOM_BLOCK + threadIdx.x + 1;
+    const int ilay = blockIdx.y + 1;
+    if (!cell_slot(d, ipnt)) return;
+    const int c5 = d.neig[8ll * ipnt + 4], c7 = d.neig[8ll * ipnt + 6];
+    const int nl = d.nlay;                     // the reference's 2-D d2hx, d2hy: as the LAST Montgomery sweep (layer nlay) left them
+    double hcen = (LL(d.hlay, c5, ilay) + LL(d.hlay, ipnt, ilay)) / (1.0 + d.mk_u[ipnt]);
+    const double uu = LL(d.u, ipnt, ilay);
+    LL(d.h_u, ipnt, ilay) = 0.5 * (uu + fabs(uu)) * (hcen - 0.16667 * LL(d.d2hx, c5, nl))
+                          + 0.5 * (uu - fabs(uu)) * (hcen - 0.16667 * LL(d.d2hx, ipnt, nl));
+    hcen = (LL(d.hlay, c7, ilay) + LL(d.hlay, ipnt, ilay)) / (1.0 + d.mk_v[ipnt]);
+    const double vv = LL(d.v, ipnt, ilay);
+    LL(d.h_v, ipnt, ilay) = 0.5 * (vv + fabs(vv)) * (hcen - 0.16667 * LL(d.d2hy, c7, nl))
+                          + 0.5 * (vv - fabs(vv)) * (hcen - 0.16667 * LL(d.d2hy, ipnt, nl));
+}
+// right-hand side of the Poisson equation (:1723-1755).  The reference scatters (pi_rhs(ipnt) -= f, pi_rhs(c5) += f) in
+// packed order, layer by layer; per cell that is a fixed sequence of at most four terms per layer — the own one at "time"
+// ipnt, the eastern (northern) neighbour's at that neighbour's index — gathered here in exactly that order.
+__global__ __launch_bounds__(BEOM_BLOCK) void k_rgld_rhs(DevView d) {
+    const int ipnt = blockIdx.x * BEOM_BLOCK + threadIdx.x + 1;
+    if (!cell_slot(d, ipnt)) return;
+    const double den = d.dl * d.dt;
+    const int c1 = d.neig[8ll * ipnt + 0], c3 = d.neig[8ll * ipnt + 2];
+    const bool own_x = d.subc[ipnt] > 1, own_y = d.subc[ipnt + d.n1] > 1;
+    const bool from_e = c1 != 0 && d.subc[c1] > 1 && d.neig[8ll * c1 + 4] == ipnt;
+    const bool from_n = c3 != 0 && d.subc[c3 + d.n1] > 1 && d.neig[8ll * c3 + 6] == ipnt;
+    // order of the serial loop = order of the CALLER's packed indices
+    const long long me = packed_index0(d, ipnt), pe = from_e ? packed_index0(d, c1) : 0, pn = from_n ? packed_index0(d, c3) : 0;
+    double r = 0.0;
+    for (int ilay = d.nlay; ilay >= 1; --ilay) {
+        if (from_e && pe < me) r = r + LL(d.h_u, c1, ilay) / den;
+        if (own_x) r = r - LL(d.h_u, ipnt, ilay) / den;
+        if (from_e && pe > me) r = r + LL(d.h_u, c1, ilay) / den;
+        if (from_n && pn < me) r = r + LL(d.h_v, c3, ilay) / den;
+        if (own_y) r = r - LL(d.h_v, ipnt, ilay) / den;
+        if (from_n && pn > me) r = r + LL(d.h_v, c3, ilay) / den;
+    }
+    d.pi_rhs[ipnt] = r;
+}
+// Gauss-Seidel sweeps in packed order (rp = 1, :1757-1802) as wavefronts over the anti-diagonals i + j: a cell reads the
+// NEW pressure of its W and S neighbours and the OLD one of E and N, exactly what the serial loop does.  ONE workgroup
+// (the whole iteration, convergence test included, stays on the device): meant for the small frames this option is run on.
+#define SOR_THREADS 1024
+__global__ __launch_bounds__(SOR_THREADS) void k_rgld_sor(DevView d) {
+    __shared__ double s_red[SOR_THREADS / 64];
+    __shared__ double s_max;
+    const double rp = 1.000, pi_tol = 1.e-5;
+    const int maxiters = 1000, tid = threadIdx.x;
+    double maxdiff = pi_tol + 1;
+    int iters = 0;
+    while (maxdiff > pi_tol && iters < maxiters) {
+        double mine = 0.0;
+        for (int dg = 0; dg < d.sor_ndiag; ++dg) {
+            for (int k = d.sor_dstart[dg] + tid; k < d.sor_dstart[dg + 1]; k += SOR_THREADS) {
+                const int ipnt = d.sor_order[k];
+                const int i = d.subc[ipnt], j = d.subc[ipnt + d.n1];
+                const int32_t *nb = d.neig + 8ll * ipnt;
+                const double old = d.pi_s[ipnt], os_ = d.Osum_[ipnt];
+                double x = (1 - rp) * old - rp * os_ * d.pi_rhs[ipnt];
+                if (i < d.lm) { const int c1 = nb[0]; x = x + rp * os_ * d.Ow[c1] * d.pi_s[c1]; }
+                if (j < d.mm) { const int c3 = nb[2]; x = x + rp * os_ * d.Os[c3] * d.pi_s[c3]; }
+                if (i > 1) { const int c5 = nb[4]; x = x + rp * os_ * d.Ow[ipnt] * d.pi_s[c5]; }
+                if (j > 1) { const int c7 = nb[6]; x = x + rp * os_ * d.Os[ipnt] * d.pi_s[c7]; }
+                d.pi_s[ipnt] = x;
+                const double diff = fabs(x - old);
+                if (diff > mine) mine = diff;
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
+        for (int off = 32; off > 0; off >>= 1) mine = fmax(mine, __shfl_down(mine, off, 64));
+        if ((tid & 63) == 0) s_red[tid >> 6] = mine;
+        __syncthreads();
+        if (tid == 0) { double m = s_red[0]; for (int w = 1; w < SOR_THREADS / 64; ++w) m = fmax(m, s_red[w]); s_max = m; }
+        __syncthreads();
+        maxdiff = s_max;
+        iters = iters + 1;
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(BEOM_BLOCK) void k_rgld_correct(DevView d) {                    // :1806-1833
+    const int ipnt = blockIdx.x * BEOM_BLOCK + threadIdx.x + 1;
+    const int ilay = blockIdx.y + 1;
+    if (!cell_slot(d, ipnt)) return;
+    const int i = d.subc[ipnt], j = d.subc[ipnt + d.n1];
+    if (i > 1 && i < d.lm + 1) {
+        const int c5 = d.neig[8ll * ipnt + 4];
+        double uu = LL(d.u, ipnt, ilay) - d.dt / d.dl * d.pi_s[ipnt];
+        LL(d.u, ipnt, ilay) = uu + d.dt / d.dl * d.pi_s[c5];
+    }
+    if (j > 1 && j < d.mm_glob + 1) {
+        const int c7 = d.neig[8ll * ipnt + 6];
+        double vv = LL(d.v, ipnt, ilay) - d.dt / d.dl * d.pi_s[ipnt];
+        LL(d.v, ipnt, ilay) = vv + d.dt / d.dl * d.pi_s[c7];
+    }
 }
 
 // ---- biharmonic viscosity, update_viscosity's svis > 0 part (private_mod.f95:2508-2599).

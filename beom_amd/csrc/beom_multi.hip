@@ -682,7 +682,7 @@ int beom_multi_download_state(beom_multi_handle M, double *hlay, double *u, doub
 //      beom_download_diag with GLOBAL (ndeg, nlay) real*4 records; every band forms its rows on its device.
 namespace {
 // (ndeg, nlay) records have no sentinel: cell (row r, column i) of layer k at (i-1) + (r-1)*L + ndeg*(k-1)
-std::vector<float> cut_rec(const float *x, int nl, size_t ndeg_g, const std::vector<int> &rows, int L) {
+static std::vector<float> cut_rec(const float *x, int nl, size_t ndeg_g, const std::vector<int> &rows, int L) {
     std::vector<float> z;
     if (!x) return z;
     const size_t nloc = rows.size() * (size_t)L;

@@ -8,8 +8,9 @@
 ! state, own routine structure; citations `:NNNN` point at the reference routine
 ! (private_mod.f95) whose observable behaviour a block reproduces.
 !
-! Not offered on the GPU path, refused with errc < 0 like any other bad option:
-! rgld = 1 (rigid lid).  The fork's extra
+! rgld = 1 (the fork's rigid lid) runs on one device with ocrp = 1 (the only setting in which the reference
+! initialises the lid's Poisson operators, :505-563); other combinations are refused with errc < 0 like any
+! other bad option.  The fork's extra
 ! switches svis/tdrg/topt are not declared by the reference's own shared_mod.f95
 ! (SURVEY F2), so by default this host does not reference them (= 0).  With a shared_mod.f95
 ! that does declare them, compile with `-cpp -DBEOM_FORK_SWITCHES` (build_host.py does this
@@ -39,6 +40,7 @@ module private_mod
     nudg(:,:), fnud(:,:,:), hdot(:,:), tide(:,:,:,:), bodf(:,:), taus(:,:),           &
     hlay(:,:), u(:,:), v(:,:), h_u(:,:), h_v(:,:), rs_h(:,:,:), dmdx(:,:,:),          &
     dmdy(:,:,:), v_cc(:,:), v_ll(:,:), tt3d(:,:,:), tb3d(:,:,:), tu3d(:,:,:)
+  real(c_double), allocatable, target :: lid_p(:), lid_w(:), lid_s(:), lid_inv(:)   ! rgld = 1: pi_s, Ow, Os, 1/Osum (:64-67, 91)
   real(r4), allocatable, target :: h0r4(:,:)      ! what h_0.bin holds (ndeg, nlay)
   real(r4), allocatable, target :: rec_eta(:,:), rec_u(:,:), rec_v(:,:)   ! records formed on the GPU
   real(c_double), allocatable, target :: mnmx(:,:) ! (6, nlay): min/max of h, u, v per layer
@@ -122,6 +124,8 @@ subroutine setup_state()
     write(ioso, *) 'Completed the calculation of h_0.'
   end if
 
+  if ( rgld > 0.5_rw ) call lid_operators( h_0 )
+
   allocate( h0r4(ndeg, nlay) )
   h0r4 = real( h_0(1:, :), r4 )
   call put_record_r4( 'h_0.bin', 1, h0r4, fresh = .true. )
@@ -157,6 +161,45 @@ subroutine setup_state()
   if ( errc /= 0 ) call quit()
   errm = errm(1:lerm)
 end subroutine setup_state
+
+! ---- rigid lid: start pressure and the west / south / inverse-sum operators of its Poisson equation (:505-563) ----
+subroutine lid_operators(h_0)
+  real(r8), intent(in) :: h_0(0:, :)
+  real(rw), allocatable :: total(:)
+  real(rw) :: column
+  integer  :: n, k, i, j
+  logical  :: in_x, in_y
+  allocate( lid_p(0:ndeg), lid_w(0:ndeg), lid_s(0:ndeg), lid_inv(0:ndeg), total(0:ndeg) )
+  lid_w = 0._rw;  lid_s = 0._rw;  lid_inv = 0._rw;  total = 0._rw
+  do n = 0, ndeg                                                 ! rest column minus depth, as a pressure
+    column = h_0(n, 1)
+    do k = 2, nlay
+      column = column + h_0(n, k)
+    end do
+    lid_p(n) = ( column - h_th(n) ) * grav
+  end do
+  do n = 1, ndeg                                                 ! faces inside the frame carry the mean depth / dl**2
+    i = subc(n, 1);  j = subc(n, 2)
+    in_x = 1 < i .and. i < lm + 1
+    in_y = 1 < j .and. j < mm + 1
+    if ( in_x .and. (in_y .or. j == 1) ) lid_w(n) = 0.5_rw * ( h_th(n) + h_th(neig(5, n)) ) / dl**2
+    if ( in_y .and. (in_x .or. i == 1) ) lid_s(n) = 0.5_rw * ( h_th(n) + h_th(neig(7, n)) ) / dl**2
+  end do
+  do n = 1, ndeg
+    i = subc(n, 1);  j = subc(n, 2)
+    if ( i < lm .and. j < mm ) then
+      total(n) = lid_w(n) + lid_w(neig(1, n)) + lid_s(n) + lid_s(neig(3, n))
+    else if ( i == lm .and. j < mm ) then
+      total(n) = lid_w(n) + lid_s(n) + lid_s(neig(3, n))
+    else if ( j == mm .and. i < lm ) then
+      total(n) = lid_w(n) + lid_s(n) + lid_w(neig(1, n))
+    else
+      total(n) = lid_w(n) + lid_s(n)
+    end if
+    if ( i > 0 .and. i < lm + 1 .and. j > 0 .and. j < mm + 1 ) lid_inv(n) = 1 / total(n)
+  end do
+  deallocate( total )
+end subroutine lid_operators
 
 subroutine allocate_defaults()                                   ! initialize_variables (:252-307)
   allocate( neig(8, 0:ndeg), subc(0:ndeg, 2), posc(ndeg) )
@@ -218,7 +261,8 @@ subroutine check_options()                                       ! check_consist
                    '0 <= tdrg < 5x10**(-3) x u_max.' )
   end if
 #endif
-  if ( rgld > 0.5_rw ) call fail( -5, 'rgld = 1 (rigid lid) is not available on the MI355X path.' )
+  if ( rgld > 0.5_rw .and. ocrp < 0.5_rw ) &
+    call fail( -5, 'rgld = 1 (rigid lid) needs ocrp = 1: the lid operators are only set up with outcropping.' )
   if ( nlay > beom_max_layers ) call fail( -3, 'nlay exceeds BEOM_MAX_LAYERS of libbeom_hip.' )
 end subroutine check_options
 
@@ -928,6 +972,7 @@ subroutine write_field(var, fresh)                               ! write_array (
         end if
       end do
     end do
+    if ( rgld > 0.5_rw ) a(:, 1) = real( lid_p(1:) )             ! the lid pressure in the top record (:2864-2872)
   case ( 'u___' )
     a = real( u(1:, :), r4 )
   case ( 'v___' )
@@ -1032,6 +1077,10 @@ subroutine gpu_start()
   if ( nudging_on .and. mcbc < 0.5_rw ) then                     ! no_gradient_obc (:2613-2679) on the device
     rc = beom_set_open_boundaries( gpu, int(size(segm, 1), c_int), c_loc(segm), cmsg, int(lstr, c_int) )
     call gpu_check( rc, cmsg, 'beom_set_open_boundaries' )
+  end if
+  if ( rgld > 0.5_rw ) then                                      ! surf_pressure (:1705-1838) on the device
+    rc = beom_set_rigid_lid( gpu, c_loc(lid_w), c_loc(lid_s), c_loc(lid_inv), c_loc(lid_p), cmsg, int(lstr, c_int) )
+    call gpu_check( rc, cmsg, 'beom_set_rigid_lid' )
   end if
   rc = beom_upload_state( gpu, c_loc(hlay), c_loc(u), c_loc(v), c_loc(h_u), c_loc(h_v), c_loc(rs_h), &
                           c_loc(dmdx), c_loc(dmdy), c_loc(v_cc), c_loc(v_ll), c_loc(tt3d),           &

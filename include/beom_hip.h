@@ -137,6 +137,19 @@ int beom_download_outputs(beom_handle h, const float *h0r4, float *eta, float *u
  * each (ndeg, nlay) real*4, any pointer may be NULL.  Call between time steps (uses the step's scratch arrays). */
 int beom_download_diag(beom_handle h, float *pvor, float *mont, float *v_cc, char *errm, int errm_len);
 
+/* Rigid lid (rgld = 1; the fork's addition, private_mod.f95:64-67, 91, 505-563, 1648-1700, 1705-1838, 2207-2221,
+ * 2237-2257, 2292-2314).  A handle created with prm->rgld = 1 (needs variant 0, ocrp = 1 — the reference only
+ * initialises the operators then — and a whole frame) steps as the reference does: transports rebuilt before update_h
+ * and after the momentum sweeps, the column-misfit epilogue of update_h, then surf_pressure — the Poisson right-hand
+ * side, Gauss-Seidel sweeps in packed order until max|change| <= 1e-5 or 1000 sweeps (on the device as wavefronts over
+ * the anti-diagonals, same arithmetic), and the velocity correction.  beom_set_rigid_lid uploads the module arrays
+ * Ow, Os, Osum_ (0:ndeg) (first call: required) and the lid pressure pi_s(0:ndeg) (NULL: keep; zero after create);
+ * beom_step refuses (-6) until it has been called.  beom_download_pressure returns pi_s; beom_download_outputs puts
+ * real(pi_s) into the top 'eta_' record as write_array does (:2864-2872). */
+int beom_set_rigid_lid(beom_handle h, const double *Ow, const double *Os, const double *Osum_, const double *pi_s,
+                       char *errm, int errm_len);
+int beom_download_pressure(beom_handle h, double *pi_s, char *errm, int errm_len);
+
 /* The six per-layer diagnostics of update_mont_rvor_pvor_dive_kine, which the library
  * keeps per layer: each is (0:ndeg, nlay).  (The reference keeps (0:ndeg) and reuses it
  * layer after layer, private_mod.f95:48-61.) */

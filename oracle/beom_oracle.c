@@ -658,7 +658,7 @@ int oracle_step(const beom_params *P, oracle_state *S, int tstp_first, int nstep
             const double c1 = tres + dtd8 * 1.0;
             if (rsta < 0.5 && c1 < dt_r) ramp = c1 / dt_r;
         }
-        const double gene = (first3 || P->rgld > 0.5) ? 0.0 : P->g_fb;       /* :1859,1877; :1880-1884: no multistep with a lid */
+        const double gene = (first3 || (P->g_fb > 0.5 && P->rgld > 0.5)) ? 0.0 : P->g_fb;       /* :1859,1877; :1880-1884: no multistep with a lid */
         oracle_one_step(P, S, tstp, first3, upst, gene, ramp, ctim);
     }
     return 0;

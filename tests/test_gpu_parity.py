@@ -53,7 +53,7 @@ def _engine(f, variant=0, mode="dense_fused", **kw):
 def _fuses(p):
     """Montgomery(+Leith) runs as the fused sweep for this configuration (beom_engine.hip can_fuse): the
     viscosity is refreshed every step, or never after step 3."""
-    if float(p.svis) > 0.0 or p.nlay > 8:
+    if float(p.svis) > 0.0 or p.nlay > 8 or float(p.rgld) > 0.5:      # (a rigid-lid handle keeps the separate sweeps)
         return False
     return True
 
@@ -86,6 +86,8 @@ def test_step_matches_reference_golden(name, mode):
         keys = SCRATCH if not lossy else (("mont", "pvor") if mode in ("dense_fused", "dense_fused_muv") else ("mont", "pvor", "d2hx", "d2hy"))
         for k in keys:                                                        # reference scratch = last layer
             _check(sc[k][g.p.nlay - 1], g.step(tgt, k), exact, (name, tgt, k))
+        if float(g.p.rgld) > 0.5:                  # rigid lid: the pressure the Gauss-Seidel sweeps converged to
+            assert same_bits(e.download_pressure(), g.step(tgt, "pi_s")), (name, tgt, "pi_s")
     e.close()
 
 
@@ -227,6 +229,52 @@ def test_land_frames_on_the_rectangle_match_oracle_and_table_path(case):
     emb.close(); tab.close()
 
 
+@pytest.mark.parametrize("case", ["sill_3l", "basin_coast_wind_2l", "sill_xper_2l"])
+def test_rigid_lid_larger_frames_match_oracle(case):
+    """rgld = 1 (private_mod.f95:1648-1700, 1705-1838, 2207-2221, 2237-2257, 2292-2314) on frames wider than one tile,
+    with land (the rectangle form and the table path; a straight coast — the reference's operators are 1/0 at any coast
+    cell whose four faces are dry, e.g. around an island) and with an x-periodic seam (where the reference's serial scatter
+    of the Poisson right-hand side meets its eastern neighbour BEFORE its own term; the reference's lid is not made for
+    periodic frames and the run diverges, so only the 7 steps that stay finite): states, transports and the lid pressure
+    the Gauss-Seidel wavefronts converge to, bit for bit against the oracle's serial sweeps, through a restart."""
+    from beom_amd import inputs as I
+    from beom_amd.grid import read_input_data
+    if case == "sill_3l":
+        p, files = I.case_sill_exchange3d(lm=133, mm=41, nlay=3, dt_s=0.01, npts=5, sill_halfwidth=6.0)
+        p = p.replace(rgld="1.")
+    elif case == "sill_xper_2l":
+        p, files = I.case_sill_exchange3d(lm=70, mm=37, nlay=2, dt_s=0.01, npts=5, sill_halfwidth=6.0)
+        p = p.replace(rgld="1.", xper="1.")
+    else:
+        p, files = I.case_headline(150, 60, 2)
+        p = p.replace(rgld="1.", ocrp="1.", bdrg="2.e-4", tauw=["0.05", "0.02"], g_fb="0.")
+        files = {k: np.array(v, dtype=np.float64) for k, v in files.items()}
+        h = files["h_bo"]
+        h[:, int(0.8 * p.mm) + 1:] = 0.0             # land north of row 0.8 mm
+        p = p.replace(ndeg=I.get_nbr_deg_freedom(h))
+    f = read_input_data(p, files=files)
+    assert float(f.p.rgld) > 0.5 and np.abs(f.Osum_).max() > 0 and np.isfinite(f.Osum_).all()
+    fast, tab, o = capi.Engine(f), capi.Engine(f, dense_hint=0), oracle_lib.Oracle(f)
+    assert fast.is_dense and not tab.is_dense and fast.is_embedded == (case == "basin_coast_wind_2l")
+    t = 1
+    for n in ((3, 4) if case == "sill_xper_2l" else (3, 4, 6)):
+        for x_ in (fast, tab, o):
+            x_.step(t, n)
+        t += n
+        if n == 4:                                   # scatter state and pressure again
+            fast.upload(**fast.download()); fast.upload_pressure(fast.download_pressure())
+        for e in (fast, tab):
+            st = e.download()
+            for k in PROGNOSTIC:
+                assert same(st[k], o.state()[k]), (case, k, t, maxrel(st[k], o.state()[k]))
+            for k in ("hlay", "u", "v", "h_u", "h_v"):
+                assert same_bits(st[k], o.state()[k]), (case, k, "sign of zero")
+            assert same_bits(e.download_pressure(), o.rgld["pi_s"]), (case, t, "pi_s")
+    eta, _, _, _, _ = fast.download_outputs(np.ascontiguousarray(f.h_0[:, 1:], dtype=np.float32))
+    assert np.array_equal(eta[0].view(np.uint32), o.rgld["pi_s"][1:].astype(np.float32).view(np.uint32))     # :2864-2872
+    fast.close(); tab.close()
+
+
 def test_restart_split_equals_single_run():
     """download → new handle → upload → continue == uninterrupted run (state incl. histories)."""
     g = Golden("sill_2l_ocrp")
@@ -294,9 +342,39 @@ def test_lean_thickness_curvature_matches_oracle(case):
 def test_unsupported_options_fail_loudly():
     g = Golden("stommel_24x16")
     f = _fields(g)
-    f.p = f.p.replace(rgld="1.")        # rigid lid: needs the elliptic solver the fork never finished
+    assert float(f.p.ocrp) < 0.5
+    f.p = f.p.replace(rgld="1.")        # rigid lid without outcropping: the reference never initialises the operators (:505)
     with pytest.raises(capi.BeomError):
         capi.Engine(f)
+
+
+def test_rigid_lid_needs_its_operators():
+    """A rgld = 1 handle refuses to step until beom_set_rigid_lid has been called, and a free-surface handle
+    refuses the lid calls."""
+    g = Golden("rigid_lid_sill_2l")
+    f = _fields(g)
+    lib = capi.load()
+    e = capi.Engine.__new__(capi.Engine)
+    import ctypes as C
+    e.lib, e.f, e.p, e.device = lib, f, f.p, 0
+    e.prm = capi.make_params_struct(f.p, f, 0, 1, 0, 0)
+    e._err = C.create_string_buffer(capi.ERRLEN + 1)
+    e.h = C.c_void_p()
+    opt = lambda k: capi._dp(getattr(f, k)) if f.has.get(k, True) else None
+    rc = lib.beom_create(C.byref(e.prm), 0, capi._ip(f.neig), capi._ip(f.subc), capi._dp(f.mk_u), capi._dp(f.mk_v),
+                         capi._dp(f.mk_n), capi._dp(f.mkpe), capi._dp(f.mkpi), capi._dp(f.fcor), capi._dp(f.h_th),
+                         capi._dp(f.h_to), capi._dp(f.nudg), capi._dp(f.fnud), opt("hdot"), opt("tide"), opt("bodf"),
+                         capi._dp(f.taus), C.byref(e.h), e._err, capi.ERRLEN)
+    assert rc == 0, e._err.value
+    e.upload(**{k: getattr(f, k) for k in capi.STATE_NAMES})
+    with pytest.raises(capi.BeomError, match="beom_set_rigid_lid"):
+        e.step(1, 1)
+    e.close()
+    g2 = Golden("stommel_24x16")
+    e2 = capi.Engine(_fields(g2))
+    with pytest.raises(capi.BeomError):
+        e2.download_pressure()
+    e2.close()
 
 
 def _big_cases():
