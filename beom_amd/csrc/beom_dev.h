@@ -68,10 +68,11 @@ struct DevView {
     // stress work arrays
     double *layt, *layb, *layu, *taub, *taum;
     // rigid lid (rgld = 1, private_mod.f95:505-563, 1705-1838): lid pressure, Poisson operators, right-hand side, previous
-    // iterate; the packed cells in Gauss-Seidel wavefront order (anti-diagonals i + j: what the serial sweep computes)
+    // iterate; the packed cells in Gauss-Seidel wavefront order (levels of the serial sweep's dependency graph)
     double *pi_s, *pi_rhs, *pi_prev;
     const double *Ow, *Os, *Osum_;
     const int32_t *sor_order, *sor_dstart;
+    const int32_t *lid_rhs_start, *lid_rhs_ent;  // per cell: its terms of the Poisson right-hand side in the serial loops' order (4 * source + code)
     int sor_ndiag;
     // constants by value
     double dl, dt, grav, rho0, beta, epsi, gamm, del1, del2, hmin, hsal, bvis, dvis, bdrg, tdrg,

@@ -83,7 +83,7 @@ struct beom_engine {
                                        // -1 = automatic (dense frames of at most 4 M cell-layers)
     long long graph_steps = 0, eager_steps = 0;
     // rigid lid (rgld = 1): the caller's subc and the packed -> device index map, kept for beom_set_rigid_lid
-    std::vector<int32_t> subc_host, dev_index;
+    std::vector<int32_t> subc_host, neig_host, dev_index;
     bool lid = false, lid_ready = false;
     char last_err[512] = {0};
 };
@@ -317,6 +317,7 @@ int beom_create(const beom_params *prm, int device, const int32_t *neig, const i
     E->lid = prm->rgld > 0.5;
     if (E->lid) {
         E->subc_host.assign(subc, subc + 2 * n1h);
+        E->neig_host.assign(neig, neig + 8 * n1h);
         E->dev_index.assign(n1h, 0);
         const int P = (d.L + 15) / 16 * 16;
         for (size_t p = 1; p < n1h; ++p)
@@ -591,18 +592,30 @@ int beom_set_rigid_lid(beom_handle E, const double *Ow, const double *Os, const 
         if ((rc = dev_upload(E, &d.Ow, Ow, 1, 1, errm, errm_len))) return rc;
         if ((rc = dev_upload(E, &d.Os, Os, 1, 1, errm, errm_len))) return rc;
         if ((rc = dev_upload(E, &d.Osum_, Osum_, 1, 1, errm, errm_len))) return rc;
-        // the packed cells by anti-diagonal i + j, packed order within one (any order would do there)
+        // Levels of the serial sweep's dependency graph: a cell reads the NEW pressure of the neighbours before it in packed
+        // order (it comes after them) and the OLD pressure of those after it (they come after it).  On a plain frame the
+        // levels are the anti-diagonals i + j; the wrapped neighbours of an orphan column / row cell bend them.
         const size_t n1h = (size_t)d.ndeg + 1;
-        const int ndiag = d.L + d.M + 1;                              // keys i + j in 0..L+M
-        std::vector<int32_t> start((size_t)ndiag + 1, 0), order(n1h > 1 ? n1h - 1 : 1, 0);
+        std::vector<int32_t> level(n1h, 0), after(n1h, 0);
+        int nlevel = 1;
         for (size_t p = 1; p < n1h; ++p) {
-            const int key = E->subc_host[p] + E->subc_host[p + n1h];
-            if (key < 0 || key >= ndiag) { set_err(errm, errm_len, "beom_set_rigid_lid: subc outside the frame"); return -3; }
-            ++start[(size_t)key + 1];
+            const int i = E->subc_host[p], j = E->subc_host[p + n1h];
+            const int32_t *nb = &E->neig_host[8 * p];
+            const int32_t reads[4] = {i < d.lm ? nb[0] : 0, j < d.mm_glob ? nb[2] : 0, i > 1 ? nb[4] : 0, j > 1 ? nb[6] : 0};
+            int32_t lv = after[p];
+            for (int32_t qn : reads)
+                if (qn > 0 && (size_t)qn < p) lv = std::max(lv, level[(size_t)qn] + 1);
+            level[p] = lv;
+            for (int32_t qn : reads)
+                if (qn > 0 && (size_t)qn > p) after[(size_t)qn] = std::max(after[(size_t)qn], lv + 1);
+            nlevel = std::max(nlevel, lv + 1);
         }
+        const int ndiag = nlevel;
+        std::vector<int32_t> start((size_t)ndiag + 1, 0), order(n1h > 1 ? n1h - 1 : 1, 0);
+        for (size_t p = 1; p < n1h; ++p) ++start[(size_t)level[p] + 1];
         for (int k = 0; k < ndiag; ++k) start[(size_t)k + 1] += start[k];
         std::vector<int32_t> fill(start.begin(), start.end() - 1);
-        for (size_t p = 1; p < n1h; ++p) order[(size_t)fill[E->subc_host[p] + E->subc_host[p + n1h]]++] = E->dev_index[p];
+        for (size_t p = 1; p < n1h; ++p) order[(size_t)fill[(size_t)level[p]]++] = E->dev_index[p];
         int32_t *q = nullptr;
         if ((rc = dev_alloc(E, &q, order.size(), errm, errm_len, false))) return rc;
         HIP_TRY(hipMemcpyAsync(q, order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice, E->stream));
@@ -611,6 +624,39 @@ int beom_set_rigid_lid(beom_handle E, const double *Ow, const double *Os, const 
         HIP_TRY(hipMemcpyAsync(q, start.data(), start.size() * sizeof(int32_t), hipMemcpyHostToDevice, E->stream));
         d.sor_dstart = q;
         d.sor_ndiag = ndiag;
+        // the terms of every cell's right-hand side in the order of the serial scatter loops (:1727-1752): the x loop over
+        // the packed cells, then the y loop; a cell with i > 1 (j > 1) subtracts its transport from itself and adds it to neig(5)
+        // (neig(7)); what goes to the sentinel is dropped
+        if ((long long)d.n1 >= (1ll << 29)) { set_err(errm, errm_len, "beom_set_rigid_lid: frame too large for the lid's tables"); return -3; }
+        std::vector<int32_t> cnt((size_t)d.n1 + 2, 0);
+        for (int pass = 0; pass < 2; ++pass) {                       // pass 0: count, pass 1: fill
+            std::vector<int32_t> at;
+            std::vector<int32_t> ent;
+            if (pass) {
+                for (size_t k = 1; k < cnt.size(); ++k) cnt[k] += cnt[k - 1];          // cnt[dev] = first entry of cell dev
+                at.assign(cnt.begin(), cnt.end());
+                ent.assign((size_t)cnt.back() + 1, 0);
+            }
+            for (int dir = 0; dir < 2; ++dir)
+                for (size_t qk = 1; qk < n1h; ++qk) {
+                    if (E->subc_host[qk + dir * n1h] <= 1) continue;
+                    const int32_t src = E->dev_index[qk], tgt = E->neig_host[8 * qk + (dir ? 6 : 4)];
+                    if (!pass) { ++cnt[(size_t)src + 1]; if (tgt > 0) ++cnt[(size_t)E->dev_index[(size_t)tgt] + 1]; }
+                    else {
+                        ent[(size_t)at[src]++] = 4 * src + 2 * dir;
+                        if (tgt > 0) ent[(size_t)at[E->dev_index[(size_t)tgt]]++] = 4 * src + 2 * dir + 1;
+                    }
+                }
+            if (pass) {
+                if ((rc = dev_alloc(E, &q, cnt.size(), errm, errm_len, false))) return rc;
+                HIP_TRY(hipMemcpyAsync(q, cnt.data(), cnt.size() * sizeof(int32_t), hipMemcpyHostToDevice, E->stream));
+                d.lid_rhs_start = q;
+                if ((rc = dev_alloc(E, &q, ent.size(), errm, errm_len, false))) return rc;
+                HIP_TRY(hipMemcpyAsync(q, ent.data(), ent.size() * sizeof(int32_t), hipMemcpyHostToDevice, E->stream));
+                d.lid_rhs_ent = q;
+                HIP_TRY(hipStreamSynchronize(E->stream));
+            }
+        }
         HIP_TRY(hipStreamSynchronize(E->stream));       // (order, start are host temporaries)
         E->lid_ready = true;
     }

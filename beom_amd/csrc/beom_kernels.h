@@ -1719,32 +1719,28 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_rgld_upstream_fluxes(DevView d) 
                           + 0.5 * (vv - fabs(vv)) * (hcen - 0.16667 * LL(d.d2hy, ipnt, nl));
 }
 // right-hand side of the Poisson equation (:1723-1755).  The reference scatters (pi_rhs(ipnt) -= f, pi_rhs(c5) += f) in
-// packed order, layer by layer; per cell that is a fixed sequence of at most four terms per layer — the own one at "time"
-// ipnt, the eastern (northern) neighbour's at that neighbour's index — gathered here in exactly that order.
+// packed order, layer by layer: per cell that is a fixed sequence of terms per layer — its own at "time" ipnt, and one
+// from every cell whose neig(5) (neig(7)) it is at that cell's index (its eastern / northern neighbour; under
+// periodicity also cells of the orphan column / row).  beom_set_rigid_lid lists them per cell in exactly that order
+// (code 0: -h_u, 1: +h_u, 2: -h_v, 3: +h_v of the source cell); this kernel adds them up.
 __global__ __launch_bounds__(BEOM_BLOCK) void k_rgld_rhs(DevView d) {
     const int ipnt = blockIdx.x * BEOM_BLOCK + threadIdx.x + 1;
     if (!cell_slot(d, ipnt)) return;
     const double den = d.dl * d.dt;
-    const int c1 = d.neig[8ll * ipnt + 0], c3 = d.neig[8ll * ipnt + 2];
-    const bool own_x = d.subc[ipnt] > 1, own_y = d.subc[ipnt + d.n1] > 1;
-    const bool from_e = c1 != 0 && d.subc[c1] > 1 && d.neig[8ll * c1 + 4] == ipnt;
-    const bool from_n = c3 != 0 && d.subc[c3 + d.n1] > 1 && d.neig[8ll * c3 + 6] == ipnt;
-    // order of the serial loop = order of the CALLER's packed indices
-    const long long me = packed_index0(d, ipnt), pe = from_e ? packed_index0(d, c1) : 0, pn = from_n ? packed_index0(d, c3) : 0;
+    const int e0 = d.lid_rhs_start[ipnt], e1 = d.lid_rhs_start[ipnt + 1];
     double r = 0.0;
-    for (int ilay = d.nlay; ilay >= 1; --ilay) {
-        if (from_e && pe < me) r = r + LL(d.h_u, c1, ilay) / den;
-        if (own_x) r = r - LL(d.h_u, ipnt, ilay) / den;
-        if (from_e && pe > me) r = r + LL(d.h_u, c1, ilay) / den;
-        if (from_n && pn < me) r = r + LL(d.h_v, c3, ilay) / den;
-        if (own_y) r = r - LL(d.h_v, ipnt, ilay) / den;
-        if (from_n && pn > me) r = r + LL(d.h_v, c3, ilay) / den;
-    }
+    for (int ilay = d.nlay; ilay >= 1; --ilay)
+        for (int e = e0; e < e1; ++e) {
+            const int ent = d.lid_rhs_ent[e], src = ent >> 2, code = ent & 3;
+            const double f = (code < 2 ? LL(d.h_u, src, ilay) : LL(d.h_v, src, ilay)) / den;
+            r = (code & 1) ? r + f : r - f;
+        }
     d.pi_rhs[ipnt] = r;
 }
-// Gauss-Seidel sweeps in packed order (rp = 1, :1757-1802) as wavefronts over the anti-diagonals i + j: a cell reads the
-// NEW pressure of its W and S neighbours and the OLD one of E and N, exactly what the serial loop does.  ONE workgroup
-// (the whole iteration, convergence test included, stays on the device): meant for the small frames this option is run on.
+// Gauss-Seidel sweeps in packed order (rp = 1, :1757-1802) as wavefronts over the levels of the serial sweep's dependency
+// graph (beom_set_rigid_lid; on a plain frame the anti-diagonals i + j): a cell reads the NEW pressure of the neighbours
+// before it in packed order and the OLD one of those after it, exactly what the serial loop does.  ONE workgroup (the whole
+// iteration, convergence test included, stays on the device): meant for the small frames this option is run on.
 #define SOR_THREADS 1024
 __global__ __launch_bounds__(SOR_THREADS) void k_rgld_sor(DevView d) {
     __shared__ double s_red[SOR_THREADS / 64];
