@@ -508,8 +508,20 @@ __device__ __forceinline__ void body_mont_visc(const DevView &d, int x0, int y0,
     }
 }
 
+// Register budget of the fused Montgomery + Leith sweep: capped for THREE waves per SIMD (168 VGPRs; the 4-layer Leith form
+// would take 172 and run two).  Measured on one box, alternating builds (tools/ab_variants.sh): mont+visc 1000 -> 905 us at
+// 4096^2 x 4, 180 -> 157 us on the sill frame (Leith + outcropping), 822 -> 706 us at 8192 x 1024 x 8 despite 84-328 B of
+// scratch per lane there; a cap for four waves (128 VGPRs) spills more than it hides.
+#ifndef MV_WAVES_PER_EU
+#define MV_WAVES_PER_EU 3
+#endif
+#if MV_WAVES_PER_EU > 0
+#define MV_OCC_ATTR __attribute__((amdgpu_waves_per_eu(MV_WAVES_PER_EU)))
+#else
+#define MV_OCC_ATTR
+#endif
 template <int NL, bool LEITH = true>
-__global__ __launch_bounds__(BEOM_BLOCK) void k_mont_visc(DevView d) {
+__global__ __launch_bounds__(BEOM_BLOCK) MV_OCC_ATTR void k_mont_visc(DevView d) {
     __shared__ double s_rv[LEITH ? 2 : 1][LEITH ? MV_LDY : 1][LEITH ? MV_LDX : 1];
     __shared__ double s_dv[LEITH ? 2 : 1][LEITH ? MV_LDY : 1][LEITH ? MV_LDX : 1];
     __shared__ double s_hh[2][MV_LDY][MV_LDX];               // hlay of tile + ring
@@ -1164,8 +1176,13 @@ __device__ __forceinline__ void body_uv_fused_edge(const DevView &d, int x0, int
 }
 
 // ZV (with PROD): v_cc = v_ll = +0 everywhere — interior workgroups drop the viscous products
+#if defined(UV_WAVES_PER_EU) && UV_WAVES_PER_EU > 0
+#define UV_OCC_ATTR __attribute__((amdgpu_waves_per_eu(UV_WAVES_PER_EU)))
+#else
+#define UV_OCC_ATTR
+#endif
 template <bool FIRST_X, bool PROD, bool ZV = false>
-__global__ __launch_bounds__(UV_BLOCK) void k_uv_fused(DevView d, double gene, double ramp, double ctim) {
+__global__ __launch_bounds__(UV_BLOCK) UV_OCC_ATTR void k_uv_fused(DevView d, double gene, double ramp, double ctim) {
     __shared__ double s_h[UV_TY + 1][UV_LDX];
     __shared__ UVstage s_f[PROD ? 4 : 1];                    // (ZV: the interior workgroups use two of them, the edge ones all four)
     __shared__ double s_hl[PROD ? UV_HROWS : 1][UV_HLDX];

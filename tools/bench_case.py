@@ -13,8 +13,11 @@ def _case():
             "stommel": lambda: I.case_stommel(lm=128, mm=128, dl=100.0e3, dt_s=400.0),
             "beach": lambda: I.case_carrier_beach(lm=8192, mm=1024, nlay=8, dt_s=0.08),   # one GPU's share of config 5
             "wind": lambda: I.case_mixed_open_bc(lm=4096, mm=2048, npts=15),   # wind-driven, nudged, 2 layers
+            "headline": lambda: I.case_headline(4096, 4096, 4),
             "headline_gather": lambda: I.case_headline(4096, 4096, 4),     # same frame through the neig tables
             "headline_land": lambda: with_land(I.case_headline(4096, 4096, 4)),
+            "closed_small": lambda: I.case_headline(2048, 256, 1),         # the soliton's frame as a closed basin (no periodic seam)
+            "closed_small4": lambda: I.case_headline(1024, 128, 4),        # the same number of cell-layers in 4 layers
             }[case]()
 
 
