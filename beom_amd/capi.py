@@ -145,6 +145,7 @@ def load(path: Optional[str] = None) -> C.CDLL:
     lib.beom_graph_stats.argtypes = [H, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     lib.beom_graph_stats.restype = ci
     lib.beom_set_open_boundaries.argtypes = [H, ci, ipp, cp, ci]
+    lib.beom_multi_set_open_boundaries.argtypes = [H, ci, ipp, cp, ci]
     lib.beom_download_outputs.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, dpp, C.POINTER(ci), cp, ci]
     lib.beom_download_diag.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p, cp, ci]
     lib.beom_download_diag.restype = ci
@@ -192,7 +193,7 @@ def load(path: Optional[str] = None) -> C.CDLL:
     for name in ("beom_multi_create", "beom_multi_destroy", "beom_multi_count", "beom_multi_band",
                  "beom_multi_upload_state", "beom_multi_download_state", "beom_multi_step", "beom_multi_sync",
                  "beom_multi_stats", "beom_multi_create_ex", "beom_multi_describe", "beom_multi_engine",
-                 "beom_multi_download_outputs", "beom_multi_download_diag",
+                 "beom_multi_download_outputs", "beom_multi_download_diag", "beom_multi_set_open_boundaries",
                  "beom_multi_set_option", "beom_multi_profile_start", "beom_multi_profile_stop", "beom_rccl_unique_id", "beom_rccl_version",
                  "beom_multi_window", "beom_multi_create_local", "beom_multi_upload_local", "beom_multi_download_local"):
         getattr(lib, name).restype = ci
@@ -221,7 +222,7 @@ EXPORTS = ("beom_abi_version", "beom_device_count", "beom_device_pci_bus_id", "b
            "beom_multi_create", "beom_multi_destroy", "beom_multi_count", "beom_multi_band",
            "beom_multi_upload_state", "beom_multi_download_state", "beom_multi_step", "beom_multi_sync",
            "beom_multi_stats", "beom_multi_create_ex", "beom_multi_describe", "beom_multi_engine",
-           "beom_multi_download_outputs", "beom_multi_download_diag",
+           "beom_multi_download_outputs", "beom_multi_download_diag", "beom_multi_set_open_boundaries",
            "beom_multi_set_option", "beom_multi_profile_start", "beom_multi_profile_stop", "beom_rccl_unique_id", "beom_rccl_version",
            "beom_multi_window", "beom_multi_create_local", "beom_multi_upload_local", "beom_multi_download_local")
 
@@ -448,6 +449,9 @@ class MultiEngine:
             opt("hdot"), opt("tide"), opt("bodf"), _dp(f.taus),
             C.byref(self.h), self._err, ERRLEN)
         self._check(rc)
+        if f.flag_nudging and float(f.p.mcbc) < 0.5 and f.segm is not None:     # no_gradient_obc (:2613), dealt to the bands
+            seg = np.ascontiguousarray(f.segm, dtype=np.int32)
+            self._check(self.lib.beom_multi_set_open_boundaries(self.h, seg.shape[1], _ip(seg), self._err, ERRLEN))
         if upload:
             self.upload(**{k: getattr(f, k) for k in STATE_NAMES})
 

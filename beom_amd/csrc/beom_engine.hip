@@ -67,6 +67,7 @@ struct beom_engine {
     int any_u = 0, any_v = 0;
     long long uniform_waves = 0, total_waves = 0;   // table path: runs of 64 cells handled by offset arithmetic
     bool obc = false;                  // no_gradient_obc active (flag_nudging, mcbc < 0.5, segments set)
+    bool obc_set = false;              // beom_set_open_boundaries has been called (a band may hold no segment at all)
     bool fuse = true;                  // dense frames: Montgomery+Leith in one sweep (k_mont_visc)
     bool fuse_uv = true;               // dense frames: update_u + update_v in one sweep (k_uv_fused)
     bool lean_visc = true;             // zero viscosity (dvis = bvis = 0, v_cc = v_ll = +0): fused pair drops the viscous products
@@ -990,7 +991,7 @@ int beom_step(beom_handle E, int tstp_first, int nsteps, double tres, double dtd
               double rsta, int n_3d, char *errm, int errm_len) {
     if (!E) { set_err(errm, errm_len, "null handle"); return -1; }
     if (tstp_first < 1 || nsteps < 0 || n_3d < 1) { set_err(errm, errm_len, "beom_step: bad arguments"); return -3; }
-    if (E->P.flag_nudging && E->P.mcbc < 0.5 && !E->obc) { set_err(errm, errm_len, "beom_step: mcbc = 0 with nudging needs beom_set_open_boundaries (no_gradient_obc, private_mod.f95:2613-2679)"); return -6; }
+    if (E->P.flag_nudging && E->P.mcbc < 0.5 && !E->obc && !E->obc_set) { set_err(errm, errm_len, "beom_step: mcbc = 0 with nudging needs beom_set_open_boundaries (no_gradient_obc, private_mod.f95:2613-2679)"); return -6; }
     if (E->lid && !E->lid_ready) { set_err(errm, errm_len, "beom_step: rgld = 1 needs beom_set_rigid_lid (the Poisson operators Ow, Os, Osum_ and the lid pressure, private_mod.f95:505-563)"); return -6; }
     HIP_TRY(hipSetDevice(E->device));
     const int end = tstp_first + nsteps;
@@ -1231,9 +1232,13 @@ int beom_download_diag(beom_handle E, float *pvor4, float *mont4, float *vcc4, c
 // of nudged open-boundary segments, Fortran storage.  Activates no_gradient_obc after the
 // momentum sweeps of every step when flag_nudging and mcbc < 0.5 (:2201-2204, 2285-2288).
 int beom_set_open_boundaries(beom_handle E, int nseg, const int32_t *segm, char *errm, int errm_len) {
-    if (!E || nseg < 1 || !segm) { set_err(errm, errm_len, "beom_set_open_boundaries: bad arguments"); return -1; }
+    if (!E || nseg < 0 || (nseg > 0 && !segm)) { set_err(errm, errm_len, "beom_set_open_boundaries: bad arguments"); return -1; }
     HIP_TRY(hipSetDevice(E->device));
-    if (E->d.slab) { set_err(errm, errm_len, "beom_set_open_boundaries: not available on a j-slab"); return -6; }
+    if (nseg == 0) {                    // (a band of a frame whose segments all lie in other bands)
+        graphs_clear(E);
+        E->d.segm = nullptr; E->d.nseg = 0; E->obc = false; E->obc_set = true;
+        return 0;
+    }
     auto S = [&](int is, int col) { return segm[(size_t)is + (size_t)nseg * (col - 1)]; };
     // The reference loops are serial.  A parallel pass is equivalent iff nothing it writes is read
     // or written by another segment of the same pass: check (component, cell) sets.
@@ -1244,6 +1249,7 @@ int beom_set_open_boundaries(beom_handle E, int nseg, const int32_t *segm, char 
             const int comp = pass == 0 ? (ns ? 0 : (ew ? 1 : -1)) : (ns ? 1 : (ew ? 0 : -1));
             if (comp < 0) continue;
             const int ip = pass == 0 ? S(is, 10) : S(is, 1), in = pass == 0 ? S(is, 16) : S(is, 13);
+            if (ip == -1) continue;      // (this pass of the segment belongs to another band: beom_multi_set_open_boundaries)
             if (ip < 1 || ip > E->d.ndeg || in < 0 || in > E->d.ndeg) { set_err(errm, errm_len, "beom_set_open_boundaries: index out of range"); return -3; }
             wr.push_back(2ll * ip + comp);
             rd.push_back(2ll * in + comp);
@@ -1271,6 +1277,7 @@ int beom_set_open_boundaries(beom_handle E, int nseg, const int32_t *segm, char 
     E->d.segm = dev;
     E->d.nseg = nseg;
     E->obc = E->P.flag_nudging && E->P.mcbc < 0.5;
+    E->obc_set = true;
     return 0;
 }
 

@@ -1685,6 +1685,7 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_no_gradient_obc(DevView d, int p
     const bool ns = SEG(5) == 1, ew = SEG(4) == 1;       // northern/southern | eastern/western boundary
     const int ipnt = pass == 0 ? SEG(10) : SEG(1);
     const int in = pass == 0 ? SEG(16) : SEG(13);
+    if (ipnt < 1) return;                                // (this pass of the segment is another band's)
     // which component: pass 0 -> u on N/S boundaries, v on E/W; pass 1 -> v on N/S, u on E/W
     const bool do_u = pass == 0 ? ns : (!ns && ew);
     const bool do_v = pass == 0 ? (!ns && ew) : ns;

@@ -28,6 +28,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <array>
 #include <vector>
 
 #include "../../include/beom_hip.h"
@@ -256,7 +257,7 @@ void deal_rows(int nrows_total, int nb, int idx, int *own0, int *own1) {
     }
 }
 
-int check_frame(const beom_params *prm, int nb, int yper, char *errm, int errm_len) {
+int check_frame(const beom_params *prm, int nb, int yper, bool global_arrays, char *errm, int errm_len) {
     const int L = prm->lm + 1, Mg = prm->mm + 1;
     if (prm->abi_version != BEOM_ABI_VERSION) { m_err(errm, errm_len, "beom_multi: ABI version mismatch"); return -2; }
     if (nb < 1 || nb > 64) { m_err(errm, errm_len, "beom_multi: bad band count %d", nb); return -3; }
@@ -267,8 +268,10 @@ int check_frame(const beom_params *prm, int nb, int yper, char *errm, int errm_l
     const int ring_rows = yper ? prm->mm : Mg;
     // every band sends its outermost kGhost owned rows; band 0 of a ring also lends rows 1..kMiniLo to the companion frame
     if (ring_rows < nb * (yper ? (kGhost > kMiniLo ? kGhost : kMiniLo) : kGhost + 1)) { m_err(errm, errm_len, "beom_multi: %d rows are too few for %d bands", ring_rows, nb); return -3; }
-    if (prm->flag_nudging && prm->mcbc < 0.5) {
-        m_err(errm, errm_len, "beom_multi: mcbc = 0 (no_gradient_obc) runs on a single-device handle only");
+    if (prm->flag_nudging && prm->mcbc < 0.5 && (!global_arrays || yper)) {
+        // (the segment table is made of global cell indices: beom_multi_set_open_boundaries deals it to the bands of a handle
+        //  created from the global arrays; not for a ring of bands)
+        m_err(errm, errm_len, "beom_multi: mcbc = 0 (no_gradient_obc) needs a handle created from the global arrays of a frame not periodic in y");
         return -4;
     }
     if (yper && prm->svis > 0.0) { m_err(errm, errm_len, "beom_multi: biharmonic viscosity on a frame periodic in y runs on a single-device handle only"); return -4; }
@@ -445,7 +448,7 @@ int beom_multi_create_ex(const beom_params *prm, int ndev, const int *devices, i
     const int transport = transport_and_flags & 0xff;
     const bool whole = ndev == 1 && !(yper && (transport_and_flags & BEOM_XCHG_RING1));      // one band = the frame itself
     if (!whole) {
-        M_RC(check_frame(prm, ndev, yper, errm, errm_len));
+        M_RC(check_frame(prm, ndev, yper, true, errm, errm_len));
         if (!beom_dense::verify(L, Mg, 0, Mg, 0, xper, yper, prm->ndeg, neig, subc, mk_u, mk_v, mk_n, mkpe, mkpi)) {
             m_err(errm, errm_len, "beom_multi_create: the row decomposition needs a dense frame (interior entirely wet)");
             return -4;
@@ -527,7 +530,7 @@ int beom_multi_create_local(const beom_params *prm, int nb, int band, int device
     if (!prm || !out || !win || !win->fcor || !win->h_th || !win->nudg || !win->fnud) { m_err(errm, errm_len, "beom_multi_create_local: null argument"); return -1; }
     *out = nullptr;
     if (band < 0 || band >= nb) { m_err(errm, errm_len, "beom_multi_create_local: band %d of %d", band, nb); return -3; }
-    M_RC(check_frame(prm, nb, yper, errm, errm_len));
+    M_RC(check_frame(prm, nb, yper, false, errm, errm_len));
     const bool ring = yper != 0;
     if (ring && band == 0 && (!orphan || !orphan->fcor || !orphan->h_th || !orphan->nudg || !orphan->fnud)) {
         m_err(errm, errm_len, "beom_multi_create_local: band 0 of a frame periodic in y also carries row mm+1 (orphan statics needed)");
@@ -732,6 +735,46 @@ int beom_multi_download_outputs(beom_multi_handle M, const float *h0r4, float *e
             for (int q = 0; q < nl * 6; ++q)
                 minmax[q] = (k == 0) ? mm[q] : ((q % 2 == 0) ? std::fmin(minmax[q], mm[q]) : std::fmax(minmax[q], mm[q]));
         if (thin_layer && thin > 0 && (*thin_layer == 0 || thin < *thin_layer)) *thin_layer = thin;
+    }
+    return 0;
+}
+
+// no_gradient_obc (private_mod.f95:2613-2679) on a frame cut into bands: the table segm(nseg, 18) of beom_set_open_boundaries
+// with GLOBAL cell indices; every band gets the passes of the segments whose updated cell and source cell lie in its rows
+// (owned or ghost), re-indexed to its window.  A band's step applies them after its momentum sweeps, as the single handle does
+// (such steps are not split: the exchange follows the whole step).
+int beom_multi_set_open_boundaries(beom_multi_handle M, int nseg, const int32_t *segm, char *errm, int errm_len) {
+    if (!M || nseg < 1 || !segm) { m_err(errm, errm_len, "beom_multi_set_open_boundaries: bad arguments"); return -1; }
+    if (M->local_mode || M->ring) { m_err(errm, errm_len, "beom_multi_set_open_boundaries: needs a handle created from the global arrays of a frame not periodic in y"); return -3; }
+    if (M->nb == 1) return beom_set_open_boundaries(M->eng[0], nseg, segm, errm, errm_len);
+    const int L = M->P.lm + 1;
+    auto S = [&](int is, int col) { return segm[(size_t)is + (size_t)nseg * (col - 1)]; };
+    for (int k = 0; k < M->n; ++k) {
+        const Band &b = M->band[k];
+        const int row0 = b.own0 - b.gs;                                     // global row of local row 1
+        // global cell index -> index in the band's window; 0 stays the sentinel; -1: outside the window
+        auto local = [&](int32_t q) -> int32_t {
+            if (q <= 0) return q == 0 ? 0 : -1;
+            const int j = (q - 1) / L + 1, i = (q - 1) % L + 1, jl = j - row0 + 1;
+            return (jl >= 1 && jl <= b.rows()) ? (int32_t)(i + (long long)(jl - 1) * L) : -1;
+        };
+        std::vector<int> keep;
+        std::vector<std::array<int32_t, 18>> rowsv;
+        for (int is = 0; is < nseg; ++is) {
+            std::array<int32_t, 18> r;
+            for (int c = 1; c <= 18; ++c) r[(size_t)c - 1] = S(is, c);
+            for (int c : {1, 7, 10, 13, 16}) r[(size_t)c - 1] = local(S(is, c));
+            if (r[9] == -1 || r[15] == -1) { r[9] = -1; r[15] = 0; }        // pass 0: updated cell (10), source (16)
+            if (r[0] == -1 || r[12] == -1) { r[0] = -1; r[12] = 0; }        // pass 1: updated cell (1), source (13)
+            if (r[6] == -1) r[6] = 0;                                       // (column 7 is not read on the device)
+            if (r[9] == -1 && r[0] == -1) continue;
+            rowsv.push_back(r);
+        }
+        const int nloc = (int)rowsv.size();
+        std::vector<int32_t> tab((size_t)nloc * 18);
+        for (int is = 0; is < nloc; ++is)
+            for (int c = 0; c < 18; ++c) tab[(size_t)is + (size_t)nloc * c] = rowsv[(size_t)is][(size_t)c];
+        M_RC(beom_set_open_boundaries(M->eng[k], nloc, nloc ? tab.data() : nullptr, errm, errm_len));
     }
     return 0;
 }

@@ -127,6 +127,16 @@ module beom_cabi
       integer(c_int)           :: rc
     end function beom_download_diag
 
+    function beom_multi_set_open_boundaries(handle, nseg, segm, errm, errm_len)                          &
+             bind(C, name = 'beom_multi_set_open_boundaries') result(rc)
+      import :: c_int, c_ptr, c_char
+      type(c_ptr), value       :: handle, segm
+      integer(c_int), value    :: nseg
+      character(kind = c_char) :: errm(*)
+      integer(c_int), value    :: errm_len
+      integer(c_int)           :: rc
+    end function beom_multi_set_open_boundaries
+
     function beom_set_rigid_lid(handle, Ow, Os, Osum_, pi_s, errm, errm_len)                              &
              bind(C, name = 'beom_set_rigid_lid') result(rc)
       import :: c_int, c_ptr, c_char

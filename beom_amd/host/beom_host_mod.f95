@@ -1062,6 +1062,10 @@ subroutine gpu_start()
                             c_loc(nudg), c_loc(fnud), p_hdot, p_tide, p_bodf, c_loc(taus), gpus, cmsg,         &
                             int(lstr, c_int) )
     call gpu_check( rc, cmsg, 'beom_multi_create' )
+    if ( nudging_on .and. mcbc < 0.5_rw ) then                   ! no_gradient_obc (:2613-2679): segments dealt to the bands
+      rc = beom_multi_set_open_boundaries( gpus, int(size(segm, 1), c_int), c_loc(segm), cmsg, int(lstr, c_int) )
+      call gpu_check( rc, cmsg, 'beom_multi_set_open_boundaries' )
+    end if
     rc = beom_multi_upload_state( gpus, c_loc(hlay), c_loc(u), c_loc(v), c_loc(h_u), c_loc(h_v), c_loc(rs_h), &
                                   c_loc(dmdx), c_loc(dmdy), c_loc(v_cc), c_loc(v_ll), c_loc(tt3d),           &
                                   c_loc(tb3d), c_loc(tu3d), cmsg, int(lstr, c_int) )

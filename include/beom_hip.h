@@ -100,7 +100,9 @@ int beom_destroy(beom_handle h);
  * Fortran storage segm[(iseg-1) + nseg*(col-1)], default integers.  With flag_nudging and
  * mcbc < 0.5 the engine then applies no_gradient_obc (:2613-2679) after the momentum sweeps of
  * every step (:2201-2204, 2285-2288); beom_step refuses such a configuration until this call
- * has been made.  Single-GPU handles only. */
+ * has been made.  nseg = 0 (segm NULL) declares that the handle holds no segment; a pass of a segment whose updated cell
+ * (column 10 for the first pass, 1 for the second) is -1 is skipped — both are what beom_multi_set_open_boundaries gives
+ * the bands of a frame.  Embedded land frames keep the table path when open boundaries are in use. */
 int beom_set_open_boundaries(beom_handle h, int nseg, const int32_t *segm, char *errm, int errm_len);
 
 /* Prognostic + history state, host -> device.  Any pointer may be NULL (left as is;
@@ -261,6 +263,12 @@ int beom_profile_steps(beom_handle h, int tstp_first, int nsteps,
                                 there is ONE band (it then exchanges with itself; exercises the ring form)   */
 
 typedef struct beom_multi *beom_multi_handle;
+
+/* no_gradient_obc (mcbc = 0) on a frame cut into bands: beom_set_open_boundaries' table with GLOBAL cell indices; the
+ * library deals the segments to the bands (a pass of a segment goes to every band whose rows hold both its updated and its
+ * source cell).  Handles created from the global arrays (beom_multi_create[_ex]) of a frame not periodic in y; steps of
+ * such a handle are not split (the exchange follows the whole step). */
+int beom_multi_set_open_boundaries(beom_multi_handle m, int nseg, const int32_t *segm, char *errm, int errm_len);
 
 /* (a) From GLOBAL arrays, all bands in this process — arguments as beom_create / beom_upload_state /
  * beom_download_state / beom_step.  Band k runs on HIP device devices[k] (with peer copies the same device may

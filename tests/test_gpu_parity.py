@@ -655,7 +655,8 @@ def test_device_side_output_records(name):
 @pytest.mark.parametrize("case,nband", [("closed_tall", 3), ("sill_tall", 2), ("stommel_tall", 2), ("soliton_xper", 2),
                                         ("beach_tall_noleith", 3), ("closed_tall_dt3d", 3),
                                         ("jet_xyper_tall", 2), ("jet_xyper_tall", 3), ("jet_yper_wind_tall", 2),
-                                        ("jet_xyper_tall", 1), ("jet_xyper_tall_rccl", 1), ("closed_tall_rccl", 1)])
+                                        ("jet_xyper_tall", 1), ("jet_xyper_tall_rccl", 1), ("closed_tall_rccl", 1),
+                                        ("sponge_obc_tall", 2), ("sponge_obc_tall", 3)])
 def test_one_process_several_bands_match_single_handle(case, nband):
     """beom_multi_* (the single-process multi-GPU form the Fortran host uses): bands of rows, ghost
     exchange by peer copy on second streams, overlapped split steps — here with every band on
@@ -663,7 +664,9 @@ def test_one_process_several_bands_match_single_handle(case, nband):
     through an upload/download round trip in the middle.
     Frames periodic in y (private_mod.f95:642-668): the bands form a ring and the orphan row mm+1 is
     carried by the companion frame; with ONE band the ring closes on itself — over peer copies, and
-    (*_rccl) over RCCL with a one-rank communicator, the only RCCL form a one-GPU box can run."""
+    (*_rccl) over RCCL with a one-rank communicator, the only RCCL form a one-GPU box can run.
+    sponge_obc_tall: nudged open boundaries with mcbc = 0 — the segments of no_gradient_obc (:2613-2679) are dealt to the bands
+    (western and eastern boundaries cross every band; the southern and northern ones belong to the first and last)."""
     from beom_amd import inputs as I
     from beom_amd.grid import read_input_data
     rccl = case.endswith("_rccl")
@@ -679,6 +682,7 @@ def test_one_process_several_bands_match_single_handle(case, nband):
         "sill_tall": lambda: I.case_sill_exchange3d(lm=133, mm=199, nlay=4, dt_s=0.01, npts=5, sill_halfwidth=20.0),
         "stommel_tall": lambda: I.case_stommel(lm=140, mm=150, dl=50.0e3, dt_s=0.2),
         "soliton_xper": lambda: I.case_soliton(lm=141, mm=63, dt_s=5.0),
+        "sponge_obc_tall": lambda: (lambda pf: (pf[0].replace(mcbc="0."), pf[1]))(I.case_wave_sponge(lx=1400.0e3, ly=1100.0e3)),
         "beach_tall_noleith": lambda: I.case_carrier_beach(lm=140, mm=260, nlay=2, dt_s=0.08),
         # Leith viscosity refreshed every 3rd step only: the bands keep v_cc, v_ll standing in between
         "closed_tall_dt3d": lambda: (lambda pf: (pf[0].replace(dt3d="%.9f" % (3.2 * float(pf[0].dt) / 86400.0)), pf[1]))(
