@@ -112,9 +112,10 @@ struct Band {
     int gs = 0, gn = 0;            // ghost rows on the south / north side
     int L = 0;                     // columns = lm + 1
     int Mr = 0;                    // rows of the ring (frames periodic in y), else 0
+    std::vector<long long> lst;    // frames with land: first local packed cell of local row j = 1..rows()+1 (rows differ in length)
     int nown() const { return own1 - own0 + 1; }
     int rows() const { return gs + nown() + gn; }
-    long long n_loc() const { return (long long)rows() * L; }
+    long long n_loc() const { return lst.empty() ? (long long)rows() * L : lst[(size_t)rows() + 1] - 1; }
     int grow(int j) const {        // global row of local row j (ghosts of a ring wrap)
         int g = own0 - gs + (j - 1);
         if (Mr) { while (g < 1) g += Mr; while (g > Mr) g -= Mr; }
@@ -160,6 +161,39 @@ void paste(T *dst, const std::vector<T> &loc, size_t outer, size_t inner, size_t
 template <class T> const T *ptr(const std::vector<T> &v) { return v.empty() ? nullptr : v.data(); }
 template <class T> T *ptr(std::vector<T> &v) { return v.empty() ? nullptr : v.data(); }
 
+// ---- the same for frames WITH land: a row is the packed range [gst[j], gst[j+1]) of the caller's arrays (packing is
+//      j-major), rows differ in length; lst = the starts of a band's rows in its own packed order ----
+template <class T>
+std::vector<T> cut_v(const T *x, size_t outer, size_t inner, size_t n1src, const std::vector<int> &rows, const std::vector<long long> &gst) {
+    std::vector<T> z;
+    if (!x) return z;
+    size_t n1l = 1;
+    for (int g : rows) n1l += (size_t)(gst[(size_t)g + 1] - gst[(size_t)g]);
+    z.resize(outer * n1l * inner);
+    for (size_t o = 0; o < outer; ++o) {
+        std::memcpy(&z[o * n1l * inner], &x[o * n1src * inner], inner * sizeof(T));
+        size_t at = 1;
+        for (int g : rows) {
+            const size_t len = (size_t)(gst[(size_t)g + 1] - gst[(size_t)g]);
+            if (len) std::memcpy(&z[(o * n1l + at) * inner], &x[(o * n1src + (size_t)gst[(size_t)g]) * inner], len * inner * sizeof(T));
+            at += len;
+        }
+    }
+    return z;
+}
+template <class T>
+void paste_v(T *dst, const std::vector<T> &loc, size_t outer, size_t inner, size_t n1dst, size_t n1l, const std::vector<long long> &lst,
+             const std::vector<long long> &gst, int j0, int n, const std::vector<int> &dst_rows, bool sentinel) {
+    if (!dst || loc.empty()) return;
+    for (size_t o = 0; o < outer; ++o) {
+        if (sentinel) std::memcpy(&dst[o * n1dst * inner], &loc[o * n1l * inner], inner * sizeof(T));
+        for (int r = 0; r < n; ++r) {
+            const size_t g = (size_t)dst_rows[(size_t)r], len = (size_t)(gst[g + 1] - gst[g]);
+            if (len) std::memcpy(&dst[(o * n1dst + (size_t)gst[g]) * inner], &loc[(o * n1l + (size_t)lst[(size_t)(j0 + r)]) * inner], len * inner * sizeof(T));
+        }
+    }
+}
+
 struct StaticsV {                  // one band's (or the companion frame's) static arrays in window layout
     std::vector<double> a[8];
     const double *bodf = nullptr;
@@ -188,6 +222,8 @@ struct beom_multi {
     bool failed = false;           // a step failed half way: the state is undefined, only destroy is allowed
     bool overlap = true;           // split steps around the exchange in flight (beom_multi_set_option "overlap")
     size_t n1g = 0;
+    bool land = false;             // a frame with land: bands are packed row ranges of unequal length, on the rectangle ("embedded") form
+    std::vector<long long> gst;    // land: first packed cell of every global row j = 1..mm+2
     std::vector<int> dev;
     std::vector<Band> band;
     std::vector<beom_handle> eng;
@@ -257,13 +293,17 @@ void deal_rows(int nrows_total, int nb, int idx, int *own0, int *own1) {
     }
 }
 
-int check_frame(const beom_params *prm, int nb, int yper, bool global_arrays, char *errm, int errm_len) {
+int check_frame(const beom_params *prm, int nb, int yper, bool global_arrays, bool land, char *errm, int errm_len) {
     const int L = prm->lm + 1, Mg = prm->mm + 1;
     if (prm->abi_version != BEOM_ABI_VERSION) { m_err(errm, errm_len, "beom_multi: ABI version mismatch"); return -2; }
     if (nb < 1 || nb > 64) { m_err(errm, errm_len, "beom_multi: bad band count %d", nb); return -3; }
-    if ((long long)prm->ndeg != (long long)L * Mg || prm->slab_mm != 0) {
-        m_err(errm, errm_len, "beom_multi: the row decomposition needs a whole dense frame (ndeg = (lm+1)(mm+1))");
+    if ((!land && (long long)prm->ndeg != (long long)L * Mg) || prm->slab_mm != 0) {
+        m_err(errm, errm_len, "beom_multi: the row decomposition needs a whole frame; one with land (ndeg < (lm+1)(mm+1)) only from the global arrays");
         return -3;
+    }
+    if (land && (yper || prm->svis > 0.0 || (prm->flag_nudging && prm->mcbc < 0.5) || prm->rgld > 0.5)) {
+        m_err(errm, errm_len, "beom_multi: bands of a frame with land: not periodic in y, no biharmonic viscosity, no mcbc = 0, no rigid lid");
+        return -4;
     }
     const int ring_rows = yper ? prm->mm : Mg;
     // every band sends its outermost kGhost owned rows; band 0 of a ring also lends rows 1..kMiniLo to the companion frame
@@ -288,6 +328,8 @@ Band make_band(const beom_params *prm, int nb, int idx, bool ring) {
     return s;
 }
 
+int finish_band(beom_multi *M, int k, char *errm, int errm_len);
+
 // one band's engine from its window statics (tables come from the closed form)
 int create_band(beom_multi *M, int k, const StaticsV &st, char *errm, int errm_len) {
     const Band &s = M->band[k];
@@ -304,6 +346,49 @@ int create_band(beom_multi *M, int k, const StaticsV &st, char *errm, int errm_l
                          ptr(st.a[5]), ptr(st.a[6]), st.bodf, ptr(st.a[7]), &M->eng[k], errm, errm_len);
     if (rc) return rc;
     if (!beom_is_dense(M->eng[k])) { m_err(errm, errm_len, "beom_multi: band %d did not qualify for the dense path", s.index); return -4; }
+    return finish_band(M, k, errm, errm_len);
+}
+
+// Band k of a frame WITH land: the rows' packed cells with the caller's own tables, re-indexed to the window (links that
+// leave the window become the sentinel: they start in the outermost ghost row, whose values nobody uses).  The engine
+// lays such a band out on its rectangle ("embedded", beom_engine.hip) — that is what the ghost-row copies rely on.
+int create_band_land(beom_multi *M, int k, const int32_t *neig, const int32_t *subc, const double *const *masks, const StaticsV &st,
+                     char *errm, int errm_len) {
+    const Band &s = M->band[k];
+    const size_t n1g = M->n1g, nloc = (size_t)s.n_loc(), n1l = nloc + 1;
+    const int row0 = s.own0 - s.gs;                               // global row of local row 1
+    const std::vector<int> rows = s.row_list();
+    auto to_local = [&](int32_t p) -> int32_t {
+        if (p <= 0) return 0;
+        const int jl = subc[(size_t)p + n1g] - row0 + 1;
+        if (jl < 1 || jl > s.rows()) return 0;
+        return (int32_t)(s.lst[(size_t)jl] + ((long long)p - M->gst[(size_t)(row0 + jl - 1)]));
+    };
+    std::vector<int32_t> ln(8 * n1l, 0), lsub(2 * n1l, 0);
+    size_t q = 1;
+    for (int g : rows)
+        for (long long p = M->gst[(size_t)g]; p < M->gst[(size_t)g + 1]; ++p, ++q) {
+            for (int c = 0; c < 8; ++c) ln[8 * q + c] = to_local(neig[8 * (size_t)p + c]);
+            lsub[q] = subc[(size_t)p];
+            lsub[q + n1l] = subc[(size_t)p + n1g] - row0 + 1;
+        }
+    std::vector<double> lm[5];
+    for (int f = 0; f < 5; ++f) lm[f] = cut_v(masks[f], 1, 1, n1g, rows, M->gst);
+    beom_params lp = M->P;
+    lp.mm = s.rows() - 1; lp.ndeg = (int32_t)nloc; lp.dense_hint = 1; lp.slab_row0 = 0; lp.slab_mm = 0;
+    int rc = beom_create(&lp, M->dev[k], ln.data(), lsub.data(), lm[0].data(), lm[1].data(), lm[2].data(), lm[3].data(), lm[4].data(),
+                         ptr(st.a[0]), ptr(st.a[1]), ptr(st.a[2]), ptr(st.a[3]), ptr(st.a[4]), ptr(st.a[5]), ptr(st.a[6]), st.bodf,
+                         ptr(st.a[7]), &M->eng[k], errm, errm_len);
+    if (rc) return rc;
+    if (beom_is_dense(M->eng[k]) != 2) {
+        m_err(errm, errm_len, "beom_multi: band %d (rows %d..%d) does not fit the rectangle form (fewer than 30 %% of its cells wet, or a coast on a periodic seam)",
+              s.index, s.own0, s.own1);
+        return -4;
+    }
+    return finish_band(M, k, errm, errm_len);
+}
+
+int finish_band(beom_multi *M, int k, char *errm, int errm_len) {
     M_HIP(hipSetDevice(M->dev[k]));
     M_HIP(hipStreamCreateWithFlags(&M->main_s[k], hipStreamNonBlocking));
     M_HIP(hipStreamCreateWithFlags(&M->comm_s[k], hipStreamNonBlocking));
@@ -447,9 +532,11 @@ int beom_multi_create_ex(const beom_params *prm, int ndev, const int *devices, i
     const int xper = neig[8 * 1 + 4] != 0, yper = neig[8 * 1 + 6] != 0;
     const int transport = transport_and_flags & 0xff;
     const bool whole = ndev == 1 && !(yper && (transport_and_flags & BEOM_XCHG_RING1));      // one band = the frame itself
+    bool land = false;
     if (!whole) {
-        M_RC(check_frame(prm, ndev, yper, true, errm, errm_len));
-        if (!beom_dense::verify(L, Mg, 0, Mg, 0, xper, yper, prm->ndeg, neig, subc, mk_u, mk_v, mk_n, mkpe, mkpi)) {
+        land = (long long)prm->ndeg != (long long)L * Mg;
+        M_RC(check_frame(prm, ndev, yper, true, land, errm, errm_len));
+        if (!land && !beom_dense::verify(L, Mg, 0, Mg, 0, xper, yper, prm->ndeg, neig, subc, mk_u, mk_v, mk_n, mkpe, mkpi)) {
             m_err(errm, errm_len, "beom_multi_create: the row decomposition needs a dense frame (interior entirely wet)");
             return -4;
         }
@@ -478,6 +565,53 @@ int beom_multi_create_ex(const beom_params *prm, int ndev, const int *devices, i
         return 0;
     }
     const double *src[8] = {fcor, h_th, h_to, nudg, fnud, hdot, tide, taus};
+    if (land) {
+        // rows as packed ranges (packing is j-major: subc's row number never decreases along the packed index)
+        M->land = true;
+        M->gst.assign((size_t)Mg + 3, 0);
+        int jprev = 1;
+        M->gst[1] = 1;
+        for (size_t p = 1; p < n1g && !rc; ++p) {
+            const int j = subc[p + n1g];
+            if (j < jprev || j > Mg) { m_err(errm, errm_len, "beom_multi_create: the packed cells are not ordered by row (cell %d)", (int)p); rc = -4; break; }
+            for (; jprev < j; ++jprev) M->gst[(size_t)jprev + 1] = (long long)p;
+        }
+        for (; jprev <= Mg + 1; ++jprev) M->gst[(size_t)jprev + 1] = (long long)n1g;
+        // bands of equal packed-cell count (balance on the cells of a row range), at least kGhost + 1 rows each
+        const int minrows = kGhost + 1;
+        int j = 1;
+        for (int k = 0; k < ndev && !rc; ++k) {
+            Band b; b.index = k; b.L = L;
+            b.own0 = j;
+            const long long target = (long long)prm->ndeg * (k + 1) / ndev;
+            const int last_allowed = Mg - (ndev - 1 - k) * minrows;
+            int e = j + minrows - 1;
+            while (e < last_allowed && M->gst[(size_t)e + 1] - 1 < target) ++e;
+            if (k == ndev - 1) e = Mg;
+            if (e > last_allowed || e < j) { m_err(errm, errm_len, "beom_multi_create: %d rows are too few for %d bands", Mg, ndev); rc = -3; break; }
+            b.own1 = e; j = e + 1;
+            b.gs = k > 0 ? kGhost : 0; b.gn = k < ndev - 1 ? kGhost : 0;
+            b.lst.assign((size_t)b.rows() + 2, 0);
+            b.lst[1] = 1;
+            for (int jl = 1; jl <= b.rows(); ++jl) {
+                const size_t g = (size_t)(b.own0 - b.gs + jl - 1);
+                b.lst[(size_t)jl + 1] = b.lst[(size_t)jl] + (M->gst[g + 1] - M->gst[g]);
+            }
+            M->band.push_back(b);
+        }
+        const double *masks[5] = {mk_u, mk_v, mk_n, mkpe, mkpi};
+        for (int k = 0; k < ndev && !rc; ++k) {
+            const std::vector<int> rows = M->band[k].row_list();
+            StaticsV st;
+            for (int f = 0; f < 8; ++f) st.a[f] = cut_v(src[f], kStatic[f].outer(nl), kStatic[f].inner, n1g, rows, M->gst);
+            st.bodf = bodf;
+            rc = create_band_land(M, k, neig, subc, masks, st, errm, errm_len);
+        }
+        if (!rc) rc = init_transport(M, nullptr, errm, errm_len);
+        if (rc) { destroy_all(M); return rc; }
+        *out = M;
+        return 0;
+    }
     for (int k = 0; k < ndev && !rc; ++k) {
         M->band.push_back(make_band(prm, ndev, k, M->ring));
         const std::vector<int> rows = M->band[k].row_list();
@@ -530,7 +664,7 @@ int beom_multi_create_local(const beom_params *prm, int nb, int band, int device
     if (!prm || !out || !win || !win->fcor || !win->h_th || !win->nudg || !win->fnud) { m_err(errm, errm_len, "beom_multi_create_local: null argument"); return -1; }
     *out = nullptr;
     if (band < 0 || band >= nb) { m_err(errm, errm_len, "beom_multi_create_local: band %d of %d", band, nb); return -3; }
-    M_RC(check_frame(prm, nb, yper, false, errm, errm_len));
+    M_RC(check_frame(prm, nb, yper, false, false, errm, errm_len));
     const bool ring = yper != 0;
     if (ring && band == 0 && (!orphan || !orphan->fcor || !orphan->h_th || !orphan->nudg || !orphan->fnud)) {
         m_err(errm, errm_len, "beom_multi_create_local: band 0 of a frame periodic in y also carries row mm+1 (orphan statics needed)");
@@ -645,7 +779,9 @@ int beom_multi_upload_state(beom_multi_handle M, const double *hlay, const doubl
         if (k < 0 && !M->mini) continue;
         const std::vector<int> rows = k < 0 ? M->mini_rows : M->band[k].row_list();
         StateV a;
-        for (int f = 0; f < 13; ++f) a.a[f] = cut(src[f], kState[f].outer(nl), kState[f].inner, n1g, rows, L);
+        for (int f = 0; f < 13; ++f)
+            a.a[f] = M->land ? cut_v(src[f], kState[f].outer(nl), kState[f].inner, n1g, rows, M->gst)
+                             : cut(src[f], kState[f].outer(nl), kState[f].inner, n1g, rows, L);
         M_RC(beom_upload_state(k < 0 ? M->mini : M->eng[k], ptr(a.a[0]), ptr(a.a[1]), ptr(a.a[2]), ptr(a.a[3]), ptr(a.a[4]), ptr(a.a[5]),
                                ptr(a.a[6]), ptr(a.a[7]), ptr(a.a[8]), ptr(a.a[9]), ptr(a.a[10]), ptr(a.a[11]), ptr(a.a[12]), errm, errm_len));
     }
@@ -675,8 +811,10 @@ int beom_multi_download_state(beom_multi_handle M, double *hlay, double *u, doub
         std::vector<int> rows;
         if (k < 0) { j0 = (int)M->mini_rows.size(); n = 1; rows.push_back(M->P.mm + 1); }      // the orphan row
         else { const Band &s = M->band[k]; j0 = s.gs + 1; n = s.nown(); for (int j = 0; j < n; ++j) rows.push_back(s.own0 + j); }
-        for (int f = 0; f < 13; ++f)
-            paste(dst[f], a.a[f], kState[f].outer(nl), kState[f].inner, n1g, n1l, L, j0, n, rows, k == 0);
+        for (int f = 0; f < 13; ++f) {
+            if (M->land) paste_v(dst[f], a.a[f], kState[f].outer(nl), kState[f].inner, n1g, n1l, M->band[k].lst, M->gst, j0, n, rows, k == 0);
+            else paste(dst[f], a.a[f], kState[f].outer(nl), kState[f].inner, n1g, n1l, L, j0, n, rows, k == 0);
+        }
     }
     return 0;
 }
@@ -694,6 +832,32 @@ static std::vector<float> cut_rec(const float *x, int nl, size_t ndeg_g, const s
         for (size_t r = 0; r < rows.size(); ++r)
             std::memcpy(&z[k * nloc + r * L], &x[k * ndeg_g + (size_t)(rows[r] - 1) * L], (size_t)L * sizeof(float));
     return z;
+}
+// (frames with land: rows as packed ranges; records have no sentinel, so cell p sits at p - 1)
+static std::vector<float> cut_rec_v(const float *x, int nl, size_t ndeg_g, const std::vector<int> &rows, const std::vector<long long> &gst) {
+    std::vector<float> z;
+    if (!x) return z;
+    size_t nloc = 0;
+    for (int g : rows) nloc += (size_t)(gst[(size_t)g + 1] - gst[(size_t)g]);
+    z.resize(nloc * nl);
+    for (int k = 0; k < nl; ++k) {
+        size_t at = 0;
+        for (int g : rows) {
+            const size_t len = (size_t)(gst[(size_t)g + 1] - gst[(size_t)g]);
+            if (len) std::memcpy(&z[k * nloc + at], &x[k * ndeg_g + (size_t)gst[(size_t)g] - 1], len * sizeof(float));
+            at += len;
+        }
+    }
+    return z;
+}
+void paste_rec_v(float *dst, const std::vector<float> &loc, int nl, size_t ndeg_g, size_t nloc, const std::vector<long long> &lst,
+                 const std::vector<long long> &gst, int j0, int n, const std::vector<int> &dst_rows) {
+    if (!dst || loc.empty()) return;
+    for (int k = 0; k < nl; ++k)
+        for (int r = 0; r < n; ++r) {
+            const size_t g = (size_t)dst_rows[(size_t)r], len = (size_t)(gst[g + 1] - gst[g]);
+            if (len) std::memcpy(&dst[k * ndeg_g + (size_t)gst[g] - 1], &loc[k * nloc + (size_t)lst[(size_t)(j0 + r)] - 1], len * sizeof(float));
+        }
 }
 void paste_rec(float *dst, const std::vector<float> &loc, int nl, size_t ndeg_g, size_t nloc, int L, int j0, int n,
                const std::vector<int> &dst_rows) {
@@ -717,8 +881,9 @@ int beom_multi_download_outputs(beom_multi_handle M, const float *h0r4, float *e
     for (int k = -1; k < M->n; ++k) {
         if (k < 0 && !M->mini) continue;
         const std::vector<int> rows = k < 0 ? M->mini_rows : M->band[k].row_list();
-        const size_t nloc = rows.size() * (size_t)L;
-        std::vector<float> h0 = cut_rec(h0r4, nl, ndeg_g, rows, L), e(eta ? nloc * nl : 0), a(u4 ? nloc * nl : 0), b(v4 ? nloc * nl : 0);
+        const size_t nloc = M->land ? (size_t)M->band[k].n_loc() : rows.size() * (size_t)L;
+        std::vector<float> h0 = M->land ? cut_rec_v(h0r4, nl, ndeg_g, rows, M->gst) : cut_rec(h0r4, nl, ndeg_g, rows, L);
+        std::vector<float> e(eta ? nloc * nl : 0), a(u4 ? nloc * nl : 0), b(v4 ? nloc * nl : 0);
         std::vector<double> mm((size_t)nl * 6);
         int thin = 0;
         M_RC(beom_download_outputs(k < 0 ? M->mini : M->eng[k], h0.data(), ptr(e), ptr(a), ptr(b), mm.data(), &thin, errm, errm_len));
@@ -726,9 +891,15 @@ int beom_multi_download_outputs(beom_multi_handle M, const float *h0r4, float *e
         std::vector<int> dst_rows;
         if (k < 0) { j0 = (int)rows.size(); n = 1; dst_rows.push_back(M->P.mm + 1); }       // the orphan row; its scans are not merged
         else { const Band &s = M->band[k]; j0 = s.gs + 1; n = s.nown(); for (int j = 0; j < n; ++j) dst_rows.push_back(s.own0 + j); }
-        paste_rec(eta, e, nl, ndeg_g, nloc, L, j0, n, dst_rows);
-        paste_rec(u4, a, nl, ndeg_g, nloc, L, j0, n, dst_rows);
-        paste_rec(v4, b, nl, ndeg_g, nloc, L, j0, n, dst_rows);
+        if (M->land) {
+            paste_rec_v(eta, e, nl, ndeg_g, nloc, M->band[k].lst, M->gst, j0, n, dst_rows);
+            paste_rec_v(u4, a, nl, ndeg_g, nloc, M->band[k].lst, M->gst, j0, n, dst_rows);
+            paste_rec_v(v4, b, nl, ndeg_g, nloc, M->band[k].lst, M->gst, j0, n, dst_rows);
+        } else {
+            paste_rec(eta, e, nl, ndeg_g, nloc, L, j0, n, dst_rows);
+            paste_rec(u4, a, nl, ndeg_g, nloc, L, j0, n, dst_rows);
+            paste_rec(v4, b, nl, ndeg_g, nloc, L, j0, n, dst_rows);
+        }
         if (k < 0) continue;
         // a band's scans cover its ghost rows too: they hold the neighbours' owned values (the exchange has landed)
         if (minmax)
@@ -789,16 +960,22 @@ int beom_multi_download_diag(beom_multi_handle M, float *pvor4, float *mont4, fl
     for (int k = -1; k < M->n; ++k) {
         if (k < 0 && !M->mini) continue;
         const std::vector<int> rows = k < 0 ? M->mini_rows : M->band[k].row_list();
-        const size_t nloc = rows.size() * (size_t)L;
+        const size_t nloc = M->land ? (size_t)M->band[k].n_loc() : rows.size() * (size_t)L;
         std::vector<float> a(pvor4 ? nloc * nl : 0), b(mont4 ? nloc * nl : 0), c(vcc4 ? nloc * nl : 0);
         M_RC(beom_download_diag(k < 0 ? M->mini : M->eng[k], ptr(a), ptr(b), ptr(c), errm, errm_len));
         int j0, n;
         std::vector<int> dst_rows;
         if (k < 0) { j0 = (int)rows.size(); n = 1; dst_rows.push_back(M->P.mm + 1); }
         else { const Band &s = M->band[k]; j0 = s.gs + 1; n = s.nown(); for (int j = 0; j < n; ++j) dst_rows.push_back(s.own0 + j); }
-        paste_rec(pvor4, a, nl, ndeg_g, nloc, L, j0, n, dst_rows);
-        paste_rec(mont4, b, nl, ndeg_g, nloc, L, j0, n, dst_rows);
-        paste_rec(vcc4, c, nl, ndeg_g, nloc, L, j0, n, dst_rows);
+        if (M->land) {
+            paste_rec_v(pvor4, a, nl, ndeg_g, nloc, M->band[k].lst, M->gst, j0, n, dst_rows);
+            paste_rec_v(mont4, b, nl, ndeg_g, nloc, M->band[k].lst, M->gst, j0, n, dst_rows);
+            paste_rec_v(vcc4, c, nl, ndeg_g, nloc, M->band[k].lst, M->gst, j0, n, dst_rows);
+        } else {
+            paste_rec(pvor4, a, nl, ndeg_g, nloc, L, j0, n, dst_rows);
+            paste_rec(mont4, b, nl, ndeg_g, nloc, L, j0, n, dst_rows);
+            paste_rec(vcc4, c, nl, ndeg_g, nloc, L, j0, n, dst_rows);
+        }
     }
     return 0;
 }

@@ -768,6 +768,60 @@ def test_output_and_diag_records_of_bands_match_single_handle(case, nband):
     one.close(); many.close()
 
 
+@pytest.mark.parametrize("case,nband", [("island_leith", 2), ("island_leith", 3), ("bay_ocrp_nudged", 3), ("island_wind_drag", 2)])
+def test_bands_of_frames_with_land_match_single_handle(case, nband):
+    """Frames WITH land cut into bands: a band is the packed range of its rows (rows differ in length), dealt by packed-cell
+    count, with the caller's own tables re-indexed to the window; every band runs the rectangle ("embedded") form and the
+    ghost rows move as rows of that rectangle.  State after 9 and 23 steps (round trip in between), the output and diag
+    records formed band by band: all equal to the single handle's bit for bit."""
+    from beom_amd import inputs as I
+    from beom_amd.grid import read_input_data
+    if case == "island_leith":
+        p, files = I.case_headline(200, 260, 3)
+    elif case == "island_wind_drag":
+        p, files = I.case_stommel(lm=200, mm=190, dl=50.0e3, dt_s=0.2)
+        files = dict(files, h_bo=np.full((202, 192), 200.0))
+    else:
+        p, files = I.case_sill_exchange3d(lm=200, mm=230, nlay=3, dt_s=0.01, npts=5, sill_halfwidth=20.0)
+    files = {k: np.array(v, dtype=np.float64) for k, v in files.items()}
+    h = files["h_bo"]
+    x = np.arange(p.lm + 2)[:, None]; y = np.arange(p.mm + 2)[None, :]
+    land = ((x - 0.3 * p.lm) ** 2 + (y - 0.55 * p.mm) ** 2) < (0.22 * p.lm) ** 2          # an island across the band seams
+    land |= (x > 0.8 * p.lm) & (y < 0.3 * p.mm) & ((x + y) % 7 != 0) if case == "bay_ocrp_nudged" else False   # a ragged corner
+    h[land] = 0.0
+    if "init" in files:
+        files["init"][land] = 0.0
+    p = p.replace(ndeg=I.get_nbr_deg_freedom(h))
+    f = read_input_data(p, files=files)
+    one, many = capi.Engine(f), capi.MultiEngine(f, devices=[0] * nband)
+    assert one.is_embedded and many.count == nband
+    bands = [many.band(k) for k in range(nband)]
+    assert bands[0]["own0"] == 1 and bands[-1]["own1"] == p.mm + 1
+    assert all(bands[k + 1]["own0"] == bands[k]["own1"] + 1 for k in range(nband - 1))
+    j = f.subc[1, 1:]                                           # dealt by packed-cell count, not by rows
+    cells = [int(((j >= b["own0"]) & (j <= b["own1"])).sum()) for b in bands]
+    assert max(cells) - min(cells) <= 2 * (p.lm + 1), cells
+    one.step(1, 9); many.step(1, 9)
+    a, b = one.download(), many.download()
+    for k in PROGNOSTIC:
+        assert same(a[k], b[k]), (case, k, "after 9 steps")
+    for k in ("hlay", "u", "v", "h_u", "h_v"):
+        assert same_bits(a[k], b[k]), (case, k, "sign of zero")
+    many.upload(**b)
+    one.step(10, 14); many.step(10, 7); many.step(17, 7)
+    a, b = one.download(), many.download()
+    for k in PROGNOSTIC:
+        assert same(a[k], b[k]), (case, k, "after 23 steps")
+    h0 = np.ascontiguousarray(f.h_0[:, 1:], dtype=np.float32)
+    ra, rb = one.download_outputs(h0), many.download_outputs(h0)
+    for x_, y_, nm in zip(ra[:3], rb[:3], ("eta", "u", "v")):
+        assert np.array_equal(x_.view(np.uint32), y_.view(np.uint32)), (case, nm)
+    assert np.array_equal(ra[3], rb[3]) and ra[4] == rb[4]
+    for x_, y_, nm in zip(one.download_diag(), many.download_diag(), ("pvor", "mont", "v_cc")):
+        assert np.array_equal(x_.view(np.uint32), y_.view(np.uint32)), (case, nm)
+    one.close(); many.close()
+
+
 def test_multi_refuses_what_it_cannot_split():
     from beom_amd import inputs as I
     from beom_amd.grid import read_input_data
@@ -784,6 +838,10 @@ def test_multi_refuses_what_it_cannot_split():
     for k in PROGNOSTIC:
         assert same(a[k], b[k]), k
     m.close(); one.close()
-    g = Golden("island_3l_forced")                                        # land: not a dense frame
+    files = {k: np.array(v, dtype=np.float64) for k, v in files.items()}  # land on a frame periodic in y: no ring of packed bands
+    files["h_bo"][15:22, 25:33] = 0.0
+    if "init" in files:
+        files["init"][15:22, 25:33] = 0.0
+    fl = read_input_data(p.replace(ndeg=I.get_nbr_deg_freedom(files["h_bo"])), files=files)
     with pytest.raises(capi.BeomError):
-        capi.MultiEngine(_fields(g), devices=[0, 0])
+        capi.MultiEngine(fl, devices=[0, 0])
