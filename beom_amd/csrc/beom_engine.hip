@@ -258,7 +258,7 @@ int beom_create(const beom_params *prm, int device, const int32_t *neig, const i
     // 0 the offset lands outside the rectangle or on a slot that is no packed cell (it then holds the sentinel's values).
     std::vector<int32_t> slot_of, pk_of;
     std::vector<unsigned char> reg4;
-    if (!E->dense && prm->dense_hint && !d.slab && prm->svis == 0.0 && getenv("BEOM_NO_EMBED") == nullptr &&
+    if (!E->dense && prm->dense_hint && prm->svis == 0.0 && getenv("BEOM_NO_EMBED") == nullptr &&      // (a band of a frame with land too: d.slab)
         !(prm->flag_nudging && prm->mcbc < 0.5) &&          // (no_gradient_obc works on the caller's segment table: table path)
         (long long)d.L * d.M < 2000000000ll && (long long)prm->ndeg * 10 >= (long long)d.L * d.M * 3) {     // (at least 30 % of the rectangle in use)
         const int L = d.L, M = d.M, P = (L + 15) / 16 * 16;
@@ -273,6 +273,7 @@ int beom_create(const beom_params *prm, int device, const int32_t *neig, const i
         }
         for (int xp = 0; xp < 2 && ok && !E->embedded; ++xp)
             for (int yp = 0; yp < 2 && !E->embedded; ++yp) {
+                if (d.slab && yp) continue;
                 const beom_dense::HostNb nb{L, M, xp, yp};
                 bool match = true;
                 for (size_t p = 1; p < n1h && match; ++p) {

@@ -375,12 +375,13 @@ int create_band_land(beom_multi *M, int k, const int32_t *neig, const int32_t *s
     std::vector<double> lm[5];
     for (int f = 0; f < 5; ++f) lm[f] = cut_v(masks[f], 1, 1, n1g, rows, M->gst);
     beom_params lp = M->P;
-    lp.mm = s.rows() - 1; lp.ndeg = (int32_t)nloc; lp.dense_hint = 1; lp.slab_row0 = 0; lp.slab_mm = 0;
+    lp.mm = s.rows() - 1; lp.ndeg = (int32_t)nloc; lp.dense_hint = 1;
+    lp.slab_row0 = row0 - 1; lp.slab_mm = M->P.mm;              // a window of the global frame: the engine splits its steps around the exchange
     int rc = beom_create(&lp, M->dev[k], ln.data(), lsub.data(), lm[0].data(), lm[1].data(), lm[2].data(), lm[3].data(), lm[4].data(),
                          ptr(st.a[0]), ptr(st.a[1]), ptr(st.a[2]), ptr(st.a[3]), ptr(st.a[4]), ptr(st.a[5]), ptr(st.a[6]), st.bodf,
                          ptr(st.a[7]), &M->eng[k], errm, errm_len);
     if (rc) return rc;
-    if (beom_is_dense(M->eng[k]) != 2) {
+    if (beom_is_dense(M->eng[k]) < 1) {           // (2: the rectangle form with land; 1: no land at all in this window)
         m_err(errm, errm_len, "beom_multi: band %d (rows %d..%d) does not fit the rectangle form (fewer than 30 %% of its cells wet, or a coast on a periodic seam)",
               s.index, s.own0, s.own1);
         return -4;

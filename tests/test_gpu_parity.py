@@ -812,6 +812,10 @@ def test_bands_of_frames_with_land_match_single_handle(case, nband):
     a, b = one.download(), many.download()
     for k in PROGNOSTIC:
         assert same(a[k], b[k]), (case, k, "after 23 steps")
+    st = many.stats()
+    assert st["split"] + st["plain"] == 23 * nband
+    if case != "island_wind_drag":                               # (a stress update every step: such steps are not split)
+        assert st["split"] >= 15 * nband, st                     # the steps run in two phases around the exchange in flight
     h0 = np.ascontiguousarray(f.h_0[:, 1:], dtype=np.float32)
     ra, rb = one.download_outputs(h0), many.download_outputs(h0)
     for x_, y_, nm in zip(ra[:3], rb[:3], ("eta", "u", "v")):
