@@ -57,7 +57,6 @@ struct DevView {
     int keep_visc;                // fused sweep (Leith) also stores v_cc, v_ll: they stand for n_3d - 1 more steps
     int zero_visc;                // v_cc = v_ll = +0 everywhere and never refreshed: the viscous products are +-0
     int lean_d2h;                 // fused sweep stores d2hx, d2hy only where the fused u+v sweep reads them
-    int supercol;                 // TileMap: an XCD sweeps its rows in column strips this many tiles wide (0: the whole width)
     int edge_global;              // k_uv_fused: edge workgroups read global memory throughout (A/B switch; default: staged by lookup)
     int only_shallow;             // k_mont_visc: only the tiles a frame-edge workgroup of k_muv reads (k_muv derives the rest itself)
     // biharmonic viscosity (svis > 0, :2508-2599): Laplacians and thickness-weighted fluxes
@@ -89,11 +88,13 @@ struct DevView {
 // A launch covers the tile rows (TY rows each) that intersect the strips; workgroups are dealt
 // to the 8 XCDs in bands of those tile rows (MI355X_MICROARCH.md: consecutive workgroups go
 // round-robin to the XCDs), so each XCD sweeps its own rows and its L2 keeps the neighbours.
-// Within its band an XCD goes strip by strip (DevView::supercol tiles wide, x fastest inside a strip): the halo rows a
-// tile row shares with the next one are then re-read after one strip row of tiles (~1 MB) instead of one full frame row
-// (several MB, more than the 4 MB L2 keeps), while tiles next to each other in x still run together.
+// Within its band an XCD sweeps whole tile rows, x fastest: HBM wants the long contiguous row streams (strips a few tiles
+// wide, which would keep the halo rows in L2, made every sweep slower: profiles/r02_ab_experiments.txt).  The tiles on the
+// frame's rim take the general paths (masks, wraps) and live longer than interior ones, so they are handed out FIRST — the
+// rim columns at the head of every tile row, the top rim row at the head of the last XCD's band — and do not form the tail
+// of a launch; done for launches of at most 4096 tiles, which are mostly tail (soliton 2048 x 256: -3 %).
 struct TileMap {
-    int tr0a, ntra, tr0b, ntrb, total, rpx, gx, sw;
+    int tr0a, ntra, tr0b, ntrb, total, rpx, gx, xlast, nlast, rim_first;
     // forceinline: an out-of-line call would take the address of the kernel argument and push all
     // of DevView (~1 KB per lane) into scratch memory
     __host__ __device__ __forceinline__ TileMap(const DevView &d, int TX, int TY) {
@@ -103,17 +104,21 @@ struct TileMap {
         if (d.nstrip > 1 && d.jhi1 >= d.jlo1) { tr0b = (d.jlo1 - 1) / TY; ntrb = (d.jhi1 - 1) / TY - tr0b + 1; }
         total = ntra + ntrb;
         rpx = (total + 7) / 8;
-        sw = (d.supercol > 0 && d.supercol < gx) ? d.supercol : gx;
+        xlast = total > 0 ? (total - 1) / rpx : 0;          // the last XCD that has tile rows, and how many
+        nlast = total - xlast * rpx;
+        rim_first = (long long)gx * total <= 4096;          // (a launch of many rounds has no tail to speak of: plain order, +0.3 % there)
     }
     __host__ unsigned blocks() const { return (unsigned)(8 * rpx * gx); }
     // blockIdx.x -> tile row (absolute) and column chunk; false if this workgroup has no tile
     __device__ __forceinline__ bool locate(int b, int &ty, int &ch) const {
         const int xcd = b & 7, k = b >> 3;
-        const int per = rpx * sw, s = k / per, rem = k - s * per;     // strip, index inside the strip
-        const int w = (gx - s * sw) < sw ? (gx - s * sw) : sw;        // (the last strip may be narrower)
-        if (w <= 0) return false;
-        const int rib = rem / w;
-        ch = s * sw + (rem - rib * w);
+        int rib = k / gx;
+        const int c = k - rib * gx;
+        ch = c;
+        if (rim_first) {
+            ch = c == 0 ? 0 : (c == 1 ? gx - 1 : c - 1);              // rim columns first
+            if (xcd == xlast && rib < nlast) rib = nlast - 1 - rib;    // the top band top-down
+        }
         const int vt = xcd * rpx + rib;
         if (rib >= rpx || vt >= total) return false;
         ty = vt < ntra ? tr0a + vt : tr0b + (vt - ntra);

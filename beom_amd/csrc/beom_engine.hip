@@ -406,7 +406,6 @@ int beom_create(const beom_params *prm, int device, const int32_t *neig, const i
     E->fuse_muv = getenv("BEOM_MUV") != nullptr;
     if (E->lid) E->fuse = E->fuse_uv = E->fuse_muv = false;      // the lid's flux rebuild reads the stored d2hx, d2hy of the last layer
     d.edge_global = getenv("BEOM_EDGE_GLOBAL") != nullptr;
-    d.supercol = getenv("BEOM_SUPERCOL") ? atoi(getenv("BEOM_SUPERCOL")) : 0;       // (measured slower at every width: DESIGN.md §4)
     E->wind = false;
     if (taus) for (size_t i = 0; i < 2 * n1h; ++i) if (std::fabs(taus[i]) > 1.e-7) { E->wind = true; break; }   // :1945
     E->bot = prm->bdrg > 1.e-7;                                                                                  // :1969
