@@ -23,12 +23,14 @@ Prints ONE JSON line (rank 0).
 from __future__ import annotations
 
 import argparse
+import datetime
 import glob
 import json
 import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -111,11 +113,26 @@ def spawn_ranks(a) -> int:
                    OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "4"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+    # a rank that dies early (fewer GPUs than ranks, a failed build) must not leave the others waiting in a rendezvous:
+    # watch them all, and stop exactly the processes started here as soon as one has failed
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = None
+    while any(p.poll() is None for p in procs):
+        bad = [p for p in procs if p.poll() not in (None, 0)]
+        if bad:
+            failed = bad[0].returncode
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            break
+        time.sleep(0.2)
+    rcs = [p.wait() for p in procs]
+    reader.join(timeout=10)
+    sys.stdout.write(b"".join(c for c in chunks if c).decode())
     sys.stdout.flush()
-    return max(abs(rc) for rc in rcs)
+    return abs(failed) if failed else max(abs(rc) for rc in rcs)
 
 
 def gpu_sensors(pci: str | None) -> dict:
@@ -175,7 +192,8 @@ def main():
         raise SystemExit("bench.py: --single-process --gpus %d but only %d GPUs visible" % (a.gpus, ndev))
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("gloo")          # control plane only; the ghost rows travel over RCCL inside the library
+        # control plane only; the ghost rows travel over RCCL inside the library
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))
 
     from beom_amd import capi, inputs, slab
     from beom_amd.grid import read_input_data
