@@ -65,8 +65,6 @@ struct DevView {
     const int32_t *woff;
     // nudged open-boundary segments, Fortran segm(nseg, 18) (no_gradient_obc, :2613-2679)
     const int32_t *segm; int nseg;
-    // stress work arrays
-    double *layt, *layb, *layu, *taub, *taum;
     // rigid lid (rgld = 1, private_mod.f95:505-563, 1705-1838): lid pressure, Poisson operators, right-hand side, previous
     // iterate; the packed cells in Gauss-Seidel wavefront order (levels of the serial sweep's dependency graph)
     double *pi_s, *pi_rhs, *pi_prev;

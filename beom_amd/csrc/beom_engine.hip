@@ -427,9 +427,6 @@ int beom_create(const beom_params *prm, int device, const int32_t *neig, const i
     AL(mont, nl * n1) AL(rvor, nl * n1) AL(pvor, nl * n1) AL(dive, nl * n1) AL(d2hx, nl * n1) AL(d2hy, nl * n1)
     if (prm->svis > 0.0) { AL(delu, nl * n1) AL(delv, nl * n1) AL(uu4, nl * n1) AL(vv4, nl * n1) }
     if (E->lid) { AL(pi_s, n1) AL(pi_rhs, n1) AL(pi_prev, n1) }
-    if (E->wind) AL(layt, nl * n1)
-    if (E->bot) { AL(layb, nl * n1) AL(taub, 2 * n1) }
-    if (E->top) { AL(layu, nl * n1) AL(taum, 2 * n1) }
 #undef AL
     // initialize_variables: v_cc = v_ll = bvis everywhere, sentinel included (:276-277)
     if (prm->bvis != 0.0) {
@@ -833,13 +830,8 @@ static void launch_lid_pressure(beom_engine *E) {
 }
 static void launch_stress(beom_engine *E) {
     if (!(E->wind || E->bot || E->top)) return;
-    const int w = E->wind, b = E->bot, t = E->top;
-    hipLaunchKernelGGL(k_stress_fractions, E->grid_cells0, dim3(BEOM_BLOCK), 0, E->stream, E->d, w, b, t);
-    for (int pass = 0; pass < 2; ++pass) {
-        if ((pass == 0 && !b) || (pass == 1 && !t)) continue;
-        hipLaunchKernelGGL(k_stress_tau, E->grid_cells0, dim3(BEOM_BLOCK), 0, E->stream, E->d, pass);
-    }
-    hipLaunchKernelGGL(k_stress_apply, E->grid_cells_layers_flat, dim3(BEOM_BLOCK), 0, E->stream, E->d, w, b, t);
+    const dim3 g((unsigned)((E->d.ncell + BEOM_BLOCK - 1) / BEOM_BLOCK));
+    hipLaunchKernelGGL(k_stress, g, dim3(BEOM_BLOCK), 0, E->stream, E->d, (int)E->wind, (int)E->bot, (int)E->top);
 }
 
 extern "C" {

@@ -1425,92 +1425,97 @@ __global__ __launch_bounds__(UV_BLOCK, 2) void k_muv(DevView d, double gene, dou
 }
 static inline dim3 muv_grid(const DevView &d) { return dim3(TileMap(d, UV_TX, UV_TY).blocks(), 1, 1); }
 
-// ---- distribute_stress, private_mod.f95:1921-2149 -----------------------------------
-// (a) layer fractions layt/layb/layu, cells 0..ndeg (the sentinel included, :1948,1972,1994)
-__global__ __launch_bounds__(BEOM_BLOCK) void k_stress_fractions(DevView d, int wind, int bot, int top) {
-    const int ipnt = blockIdx.x * BEOM_BLOCK + threadIdx.x;     // 0..ndeg
-    // embedded frames: the land slots too — a coast cell's neighbour lookup must find there what the reference finds at
-    // index 0 (e.g. layb(0, nlay) = 1), and with hlay = 0 a land slot computes exactly the sentinel's fractions
-    if (!(d.embedded ? (ipnt <= d.ncell && (ipnt == 0 || (int)((ipnt - 1) % d.P) < d.L)) : cell_slot(d, ipnt))) return;
-    const int nlay = d.nlay;
-    if (wind || top) {
-        for (int pass = 0; pass < 2; ++pass) {
-            if (pass == 0 && !wind) continue;
-            if (pass == 1 && !top) continue;
-            double *lay = pass == 0 ? d.layt : d.layu;
-            if (d.ocrp > 0.5) {
-                for (int ilay = 1; ilay <= nlay; ++ilay) {
-                    double hcum = 0.0, sofar = 0.0;
-                    for (int k = 1; k < ilay; ++k) sofar = sofar + LL(lay, ipnt, k);
-                    sofar = sofar + 0.0;                              // lay(ipnt,ilay) = 0 first (:1949,1995)
-                    for (int k = 1; k <= ilay; ++k) hcum = hcum + fmax(0.0, LL(d.hlay, ipnt, k) - 1.5 * d.hsal);
-                    double t = fmin(hcum, d.hsbl) / d.hsbl - sofar;
-                    LL(lay, ipnt, ilay) = fmax(t, 0.0);
-                }
-            } else {
-                for (int ilay = 1; ilay <= nlay; ++ilay) LL(lay, ipnt, ilay) = (ilay == 1) ? 1.0 : 0.0;
+// ---- distribute_stress, private_mod.f95:1921-2149, as ONE launch --------------------------------------------------
+// The reference forms (a) the layer fractions layt / layb / layu of every cell (:1945-2009), (b) the bottom and top stress at
+// the u / v points (:2015-2049, 2075-2109) and (c) their distribution over the layers, which reads the fractions of the W and
+// S neighbours (:2056-2071, 2116-2146).  The fractions are a function of one cell's thickness column, so a thread forms them
+// for its own cell and for its two neighbours itself (the sentinel and land slots hold hlay = 0 and give the sentinel's
+// fractions) and nothing has to wait for a neighbour's thread: one kernel instead of three or four, no work arrays.
+// Every value is computed by the reference's own sequence of operations.
+template <bool FROM_TOP>
+__device__ __forceinline__ void stress_fractions(const DevView &d, int q, double (*lay)[BEOM_BLOCK]) {
+    const int nlay = d.nlay, t = threadIdx.x;
+    if (FROM_TOP) {                                  // wind (layt) and top drag (layu): the boundary layer of depth hsbl from above
+        if (d.ocrp > 0.5) {
+            for (int ilay = 1; ilay <= nlay; ++ilay) {
+                double hcum = 0.0, sofar = 0.0;
+                for (int k = 1; k < ilay; ++k) sofar = sofar + lay[k - 1][t];
+                sofar = sofar + 0.0;                              // lay(ipnt,ilay) = 0 first (:1949,1995)
+                for (int k = 1; k <= ilay; ++k) hcum = hcum + fmax(0.0, LL(d.hlay, q, k) - 1.5 * d.hsal);
+                const double x = fmin(hcum, d.hsbl) / d.hsbl - sofar;
+                lay[ilay - 1][t] = fmax(x, 0.0);
             }
+        } else {
+            for (int ilay = 1; ilay <= nlay; ++ilay) lay[ilay - 1][t] = (ilay == 1) ? 1.0 : 0.0;
         }
-    }
-    if (bot) {
+    } else {                                         // bottom drag (layb): depth hbbl from below
         if (d.ocrp > 0.5) {
             for (int ilay = nlay; ilay >= 1; --ilay) {
                 double sofar = 0.0, hcum = 0.0;
-                sofar = sofar + 0.0;                                  // layb(ipnt,ilay) = 0 first (:1973)
-                for (int k = ilay + 1; k <= nlay; ++k) sofar = sofar + LL(d.layb, ipnt, k);
-                for (int k = ilay; k <= nlay; ++k) hcum = hcum + LL(d.hlay, ipnt, k);
-                double t = fmin(hcum, d.hbbl) / d.hbbl - sofar;
-                LL(d.layb, ipnt, ilay) = fmax(t, 0.0);
+                sofar = sofar + 0.0;                              // layb(ipnt,ilay) = 0 first (:1973)
+                for (int k = ilay + 1; k <= nlay; ++k) sofar = sofar + lay[k - 1][t];
+                for (int k = ilay; k <= nlay; ++k) hcum = hcum + LL(d.hlay, q, k);
+                const double x = fmin(hcum, d.hbbl) / d.hbbl - sofar;
+                lay[ilay - 1][t] = fmax(x, 0.0);
             }
         } else {
-            for (int ilay = 1; ilay <= nlay; ++ilay) LL(d.layb, ipnt, ilay) = (ilay == nlay) ? 1.0 : 0.0;
+            for (int ilay = 1; ilay <= nlay; ++ilay) lay[ilay - 1][t] = (ilay == nlay) ? 1.0 : 0.0;
         }
     }
 }
-
-// (b) bottom (pass 0, :2015-2049) / top (pass 1, :2075-2109) stress at u/v points, cells 0..ndeg
-//     (runs once per n_3d steps and needs the sentinel cell: always via the neig table)
-__global__ __launch_bounds__(BEOM_BLOCK) void k_stress_tau(DevView d, int pass) {
-    const int ipnt = blockIdx.x * BEOM_BLOCK + threadIdx.x;     // 0..ndeg
-    if (!cell_slot(d, ipnt)) return;
+// bottom (TOP = false, :2015-2049) / top (:2075-2109) stress at the u and v point of cell ipnt
+template <bool TOP>
+__device__ __forceinline__ void stress_tau(const DevView &d, int ipnt, double &tau_u, double &tau_v) {
     const int nlay = d.nlay;
-    int ilay = pass == 0 ? nlay : 1;
+    int ilay = TOP ? 1 : nlay;
     if (d.ocrp > 0.5) {
-        if (pass == 0) { for (int k = nlay; k >= 1; --k) if (LL(d.hlay, ipnt, k) > 2.0 * d.hsal) { ilay = k; break; } }
-        else           { for (int k = 1; k <= nlay; ++k) if (LL(d.hlay, ipnt, k) > 2.0 * d.hsal) { ilay = k; break; } }
+        if (!TOP) { for (int k = nlay; k >= 1; --k) if (LL(d.hlay, ipnt, k) > 2.0 * d.hsal) { ilay = k; break; } }
+        else      { for (int k = 1; k <= nlay; ++k) if (LL(d.hlay, ipnt, k) > 2.0 * d.hsal) { ilay = k; break; } }
     }
-    int c1 = 0, c3 = 0, c4 = 0, c5 = 0, c7 = 0, c8 = 0;
-    if (ipnt > 0) {
-        const int32_t *row = d.neig + 8ll * ipnt;
-        c1 = row[0]; c3 = row[2]; c4 = row[3]; c5 = row[4]; c7 = row[6]; c8 = row[7];
-    }
+    const int32_t *row = d.neig + 8ll * ipnt;
+    const int c1 = row[0], c3 = row[2], c4 = row[3], c5 = row[4], c7 = row[6], c8 = row[7];
     const double uu = LL(d.u, ipnt, ilay), vv = LL(d.v, ipnt, ilay);
     const double vatu = 0.25 * vv + 0.25 * LL(d.v, c3, ilay) + 0.25 * LL(d.v, c4, ilay) + 0.25 * LL(d.v, c5, ilay);
     const double uatv = 0.25 * uu + 0.25 * LL(d.u, c1, ilay) + 0.25 * LL(d.u, c7, ilay) + 0.25 * LL(d.u, c8, ilay);
-    const double drg = pass == 0 ? d.bdrg : d.tdrg;
+    const double drg = TOP ? d.tdrg : d.bdrg;
     const double rh = d.rhon[ilay - 1];
-    double *tau = pass == 0 ? d.taub : d.taum;
-    tau[ipnt]        = uu * drg * rh * (d.qdrg * sqrt(uu * uu + vatu * vatu) + 1.0 - d.qdrg);
-    tau[ipnt + d.n1] = vv * drg * rh * (d.qdrg * sqrt(vv * vv + uatv * uatv) + 1.0 - d.qdrg);
+    tau_u = uu * drg * rh * (d.qdrg * sqrt(uu * uu + vatu * vatu) + 1.0 - d.qdrg);
+    tau_v = vv * drg * rh * (d.qdrg * sqrt(vv * vv + uatv * uatv) + 1.0 - d.qdrg);
 }
-
-// (c) distribute over layers: tb3d/tu3d (:2056-2071, 2116-2133) and tt3d (:2136-2146)
-__global__ __launch_bounds__(BEOM_BLOCK) void k_stress_apply(DevView d, int wind, int bot, int top) {
-    const int ipnt = blockIdx.x * BEOM_BLOCK + threadIdx.x + 1;
-    const int ilay = blockIdx.y + 1;
-    if (!cell_slot(d, ipnt)) return;
+__global__ __launch_bounds__(BEOM_BLOCK) void k_stress(DevView d, int wind, int bot, int top) {
+    __shared__ double s_own[BEOM_MAX_LAYERS][BEOM_BLOCK], s_w[BEOM_MAX_LAYERS][BEOM_BLOCK], s_s[BEOM_MAX_LAYERS][BEOM_BLOCK];
+    const int ipnt = blockIdx.x * BEOM_BLOCK + threadIdx.x + 1, t = threadIdx.x;
+    if (!cell_slot(d, ipnt)) return;                 // (no barrier below: every thread owns its columns of the three arrays)
+    const int nlay = d.nlay;
     const int c5 = d.neig[8ll * ipnt + 4], c7 = d.neig[8ll * ipnt + 6];
+    if (wind || top) {
+        stress_fractions<true>(d, ipnt, s_own);
+        if (wind)
+            for (int ilay = 1; ilay <= nlay; ++ilay) {
+                T3_(d.tt3d, ipnt, 1, ilay) = d.taus[ipnt] * s_own[ilay - 1][t];
+                T3_(d.tt3d, ipnt, 2, ilay) = d.taus[ipnt + d.n1] * s_own[ilay - 1][t];
+            }
+        if (top) {
+            double tu, tv;
+            stress_tau<true>(d, ipnt, tu, tv);
+            stress_fractions<true>(d, c5, s_w);
+            stress_fractions<true>(d, c7, s_s);
+            for (int ilay = 1; ilay <= nlay; ++ilay) {
+                T3_(d.tu3d, ipnt, 1, ilay) = tu * 0.5 * (s_own[ilay - 1][t] + s_w[ilay - 1][t]);
+                T3_(d.tu3d, ipnt, 2, ilay) = tv * 0.5 * (s_own[ilay - 1][t] + s_s[ilay - 1][t]);
+            }
+        }
+    }
     if (bot) {
-        T3_(d.tb3d, ipnt, 1, ilay) = d.taub[ipnt] * 0.5 * (LL(d.layb, ipnt, ilay) + LL(d.layb, c5, ilay));
-        T3_(d.tb3d, ipnt, 2, ilay) = d.taub[ipnt + d.n1] * 0.5 * (LL(d.layb, ipnt, ilay) + LL(d.layb, c7, ilay));
-    }
-    if (top) {
-        T3_(d.tu3d, ipnt, 1, ilay) = d.taum[ipnt] * 0.5 * (LL(d.layu, ipnt, ilay) + LL(d.layu, c5, ilay));
-        T3_(d.tu3d, ipnt, 2, ilay) = d.taum[ipnt + d.n1] * 0.5 * (LL(d.layu, ipnt, ilay) + LL(d.layu, c7, ilay));
-    }
-    if (wind) {
-        T3_(d.tt3d, ipnt, 1, ilay) = d.taus[ipnt] * LL(d.layt, ipnt, ilay);
-        T3_(d.tt3d, ipnt, 2, ilay) = d.taus[ipnt + d.n1] * LL(d.layt, ipnt, ilay);
+        double tu, tv;
+        stress_tau<false>(d, ipnt, tu, tv);
+        stress_fractions<false>(d, ipnt, s_own);
+        stress_fractions<false>(d, c5, s_w);
+        stress_fractions<false>(d, c7, s_s);
+        for (int ilay = 1; ilay <= nlay; ++ilay) {
+            T3_(d.tb3d, ipnt, 1, ilay) = tu * 0.5 * (s_own[ilay - 1][t] + s_w[ilay - 1][t]);
+            T3_(d.tb3d, ipnt, 2, ilay) = tv * 0.5 * (s_own[ilay - 1][t] + s_s[ilay - 1][t]);
+        }
     }
 }
 
