@@ -259,7 +259,6 @@ int beom_create(const beom_params *prm, int device, const int32_t *neig, const i
     std::vector<int32_t> slot_of, pk_of;
     std::vector<unsigned char> reg4;
     if (!E->dense && prm->dense_hint && prm->svis == 0.0 && getenv("BEOM_NO_EMBED") == nullptr &&      // (a band of a frame with land too: d.slab)
-        !(prm->flag_nudging && prm->mcbc < 0.5) &&          // (no_gradient_obc works on the caller's segment table: table path)
         (long long)d.L * d.M < 2000000000ll && (long long)prm->ndeg * 10 >= (long long)d.L * d.M * 3) {     // (at least 30 % of the rectangle in use)
         const int L = d.L, M = d.M, P = (L + 15) / 16 * 16;
         slot_of.assign(n1h, 0); pk_of.assign((size_t)P * M + 1, 0);
@@ -320,6 +319,8 @@ int beom_create(const beom_params *prm, int device, const int32_t *neig, const i
     if (E->lid) {
         E->subc_host.assign(subc, subc + 2 * n1h);
         E->neig_host.assign(neig, neig + 8 * n1h);
+    }
+    if (E->lid || (E->embedded && prm->flag_nudging && prm->mcbc < 0.5)) {      // packed index -> device index, for tables uploaded later
         E->dev_index.assign(n1h, 0);
         const int P = (d.L + 15) / 16 * 16;
         for (size_t p = 1; p < n1h; ++p)
@@ -1254,8 +1255,13 @@ int beom_set_open_boundaries(beom_handle E, int nseg, const int32_t *segm, char 
     }
     // columns 1, 7, 10, 13, 16 are cell indices: to the device pitch
     std::vector<int32_t> sg(segm, segm + (size_t)nseg * 18);
-    if (E->embedded) { set_err(errm, errm_len, "beom_set_open_boundaries: internal: embedded frames keep the table path"); return -6; }
-    if (E->d.P)
+    if (E->embedded) {                   // frames with land on the rectangle: packed index -> slot
+        for (int col : {1, 7, 10, 13, 16})
+            for (int is = 0; is < nseg; ++is) {
+                int32_t &q = sg[(size_t)is + (size_t)nseg * (col - 1)];
+                if (q > 0) { if ((size_t)q >= E->dev_index.size()) { set_err(errm, errm_len, "beom_set_open_boundaries: index out of range"); return -3; } q = E->dev_index[(size_t)q]; }
+            }
+    } else if (E->d.P)
         for (int col : {1, 7, 10, 13, 16})
             for (int is = 0; is < nseg; ++is) {
                 int32_t &q = sg[(size_t)is + (size_t)nseg * (col - 1)];

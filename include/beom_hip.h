@@ -102,7 +102,7 @@ int beom_destroy(beom_handle h);
  * every step (:2201-2204, 2285-2288); beom_step refuses such a configuration until this call
  * has been made.  nseg = 0 (segm NULL) declares that the handle holds no segment; a pass of a segment whose updated cell
  * (column 10 for the first pass, 1 for the second) is -1 is skipped — both are what beom_multi_set_open_boundaries gives
- * the bands of a frame.  Embedded land frames keep the table path when open boundaries are in use. */
+ * the bands of a frame. */
 int beom_set_open_boundaries(beom_handle h, int nseg, const int32_t *segm, char *errm, int errm_len);
 
 /* Prognostic + history state, host -> device.  Any pointer may be NULL (left as is;

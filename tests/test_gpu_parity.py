@@ -99,11 +99,11 @@ def test_dense_detection(name):
     full = g.p.ndeg == (g.p.lm + 1) * (g.p.mm + 1)
     assert (e.is_dense and not e.is_embedded) == full
     # frames with land run on the same rectangle ("embedded") unless they use what only the table path has
-    # (open-boundary segments, biharmonic viscosity), the rectangle is mostly land, or a coast cell sits on a
+    # (biharmonic viscosity), the rectangle is mostly land, or a coast cell sits on a
     # periodic seam (the reference wraps row by row there, :614-640: offsets cannot express that)
     obc = bool(f.flag_nudging) and float(g.p.mcbc) < 0.5
     periodic = float(g.p.xper) > 0.5 or float(g.p.yper) > 0.5
-    if not full and not obc and not periodic and float(g.p.svis) == 0.0 and g.p.ndeg * 10 >= (g.p.lm + 1) * (g.p.mm + 1) * 3:
+    if not full and not periodic and float(g.p.svis) == 0.0 and g.p.ndeg * 10 >= (g.p.lm + 1) * (g.p.mm + 1) * 3:
         assert e.is_embedded, name
     e.close()
 
@@ -189,7 +189,7 @@ def test_graph_replay_matches_oracle_and_eager(case):
     e.close(); plain.close()
 
 
-@pytest.mark.parametrize("case", ["island_leith", "island_wind_drag", "bay_ocrp_nudged"])
+@pytest.mark.parametrize("case", ["island_leith", "island_wind_drag", "bay_ocrp_nudged", "sponge_obc_island"])
 def test_land_frames_on_the_rectangle_match_oracle_and_table_path(case):
     """Frames WITH land wide enough to have regular tiles away from the coast: the embedded form (packed cells in the
     slots of their (i, j), land slots holding the sentinel's values, masks from the caller's arrays in the tiles that
@@ -201,6 +201,11 @@ def test_land_frames_on_the_rectangle_match_oracle_and_table_path(case):
     elif case == "island_wind_drag":
         p, files = I.case_stommel(lm=400, mm=130, dl=50.0e3, dt_s=0.2)
         files = dict(files, h_bo=np.full((402, 132), 200.0))
+    elif case == "sponge_obc_island":                # nudged open boundaries with mcbc = 0 (no_gradient_obc, :2613-2679) around an island
+        p, files = I.case_wave_sponge(lx=1400.0e3, ly=1100.0e3)
+        p = p.replace(mcbc="0.")
+        depth = np.zeros((p.lm + 2, p.mm + 2)); depth[1:-1, 1:-1] = float(p.cext) ** 2 / float(p.grav)     # the default flat depth (:121), as a file
+        files = dict(files, h_bo=depth)
     else:
         p, files = I.case_sill_exchange3d(lm=400, mm=130, nlay=3, dt_s=0.01, npts=5, sill_halfwidth=20.0)
     files = {k: np.array(v, dtype=np.float64) for k, v in files.items()}
