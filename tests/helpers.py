@@ -6,6 +6,8 @@ import glob
 import json
 import os
 
+import copy
+
 import numpy as np
 
 from beom_amd.grid import read_input_data
@@ -21,6 +23,9 @@ def golden_names():
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
 
 
+_FIELDS = {}
+
+
 class Golden:
     def __init__(self, name):
         self.name = name
@@ -30,7 +35,11 @@ class Golden:
         self.files = {k[3:]: self.z[k] for k in self.z.files if k.startswith("in_")}
 
     def fields(self):
-        return read_input_data(self.p, files=self.files)
+        """The init mirror's module state for this fixture.  Built once per session and name (the outcropping rest state is an
+        iteration in numpy: seconds); callers get their own shallow copy — they set attributes (invf, p), never array elements."""
+        if self.name not in _FIELDS:
+            _FIELDS[self.name] = read_input_data(self.p, files=self.files)
+        return copy.copy(_FIELDS[self.name])
 
     def static(self, key):
         return self.z["static_" + key]

@@ -248,7 +248,7 @@ def test_rigid_lid_larger_frames_match_oracle(case):
         p, files = I.case_sill_exchange3d(lm=133, mm=41, nlay=3, dt_s=0.01, npts=5, sill_halfwidth=6.0)
         p = p.replace(rgld="1.")
     elif case == "sill_xper_2l":
-        p, files = I.case_sill_exchange3d(lm=70, mm=37, nlay=2, dt_s=0.01, npts=5, sill_halfwidth=6.0)
+        p, files = I.case_sill_exchange3d(lm=40, mm=25, nlay=2, dt_s=0.01, npts=5, sill_halfwidth=5.0)
         p = p.replace(rgld="1.", xper="1.")
     else:
         p, files = I.case_headline(150, 60, 2)
