@@ -7,7 +7,25 @@ import numpy as np
 from beom_amd import capi, inputs as I
 from beom_amd.grid import read_input_data
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 600
+
+
+def with_land(pf, sponge_obc=False):
+    """an island across the band seams and a ragged coast in one corner: bands of packed rows, dealt by cell count"""
+    p, files = pf
+    files = {k: np.array(v, dtype=np.float64) for k, v in files.items()}
+    h = files["h_bo"]
+    x = np.arange(p.lm + 2)[:, None]; y = np.arange(p.mm + 2)[None, :]
+    land = ((x - 0.3 * p.lm) ** 2 + (y - 0.55 * p.mm) ** 2) < (0.2 * p.mm) ** 2
+    land = land | ((x > 0.8 * p.lm) & (y < 0.3 * p.mm) & ((x + y) % 7 != 0))
+    h[land] = 0.0
+    if "init" in files:
+        files["init"][land] = 0.0
+    return p.replace(ndeg=I.get_nbr_deg_freedom(h)), files
+
+
 for name, mk in (("headline 4096x1024x4", lambda: I.case_headline(4096, 1024, 4)),
+                 ("headline 2048x1024x4 with land (bands of packed rows)", lambda: with_land(I.case_headline(2048, 1024, 4))),
+                 ("sill 1024x1024x3 with land (nudging, ocrp)", lambda: with_land(I.case_sill_exchange3d(lm=1024, mm=1024, nlay=3, dt_s=30.0, npts=15, sill_halfwidth=50.0))),
                  ("sill 2048x1024x4 (nudging, ocrp)", lambda: I.case_sill_exchange3d(lm=2048, mm=1024, nlay=4, dt_s=30.0, npts=15, sill_halfwidth=50.0)),
                  ("beach 4096x512x2 (no Leith)", lambda: I.case_carrier_beach(lm=4096, mm=512, nlay=2, dt_s=0.08))):
     p, files = mk()
