@@ -95,7 +95,7 @@ def source_hash() -> str:
     import hashlib
     csrc = os.path.join(_HERE, "csrc")
     h = hashlib.sha1()
-    for fn in ("beom_engine.hip", "beom_multi.hip", "beom_dev.h", "beom_kernels.h", "beom_dense_host.h",
+    for fn in ("beom_engine.hip", "beom_multi.hip", "beom_dev.h", "beom_kernels.h", "beom_launch_tiled.h", "beom_dense_host.h",
                os.path.join("..", "..", "include", "beom_hip.h")):
         with open(os.path.join(csrc, fn), "rb") as f:
             h.update(f.read())

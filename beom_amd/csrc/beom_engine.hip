@@ -13,7 +13,19 @@
 #include <string>
 #include <vector>
 
+#include "beom_dev.h"
+// the kernels, once per tile geometry (beom_launch_tiled.h): t8 also serves every kernel that is not tiled
+namespace t8 {
 #include "beom_kernels.h"
+}
+#undef MV_Q
+#undef UV_Q
+#define MV_Q 1
+#define UV_Q 1
+namespace t4 {
+#include "beom_kernels.h"
+}
+using namespace t8;
 #include "beom_dense_host.h"
 
 namespace {
@@ -86,6 +98,7 @@ struct beom_engine {
     // rigid lid (rgld = 1): the caller's subc and the packed -> device index map, kept for beom_set_rigid_lid
     std::vector<int32_t> subc_host, neig_host, dev_index;
     bool lid = false, lid_ready = false;
+    bool tile4 = false;                // the tiled sweeps run the 64 x 4 geometry (frames of one or two rounds of workgroups)
     char last_err[512] = {0};
 };
 static void graphs_clear(beom_engine *E) {
@@ -405,6 +418,11 @@ int beom_create(const beom_params *prm, int device, const int32_t *neig, const i
     E->fuse = getenv("BEOM_NO_FUSE") == nullptr;
     E->fuse_uv = getenv("BEOM_NO_FUSE") == nullptr && getenv("BEOM_NO_FUSE_UV") == nullptr;
     E->fuse_muv = getenv("BEOM_MUV") != nullptr;
+    // frames of few rounds of workgroups: the 64 x 4 tile geometry, one row per thread (a workgroup's lifetime is what the
+    // step time is made of there).  Same box, us per step, 64 x 8 -> 64 x 4: stommel 128^2 31.2 -> 24.0, soliton 2048x256
+    // 53.5 -> 43.6, 1024x128x4 74.8 -> 56.3, sill 4096x512x4 614 -> 596; jet 2048^2 x 2 535 -> 557, 4096^2 x 4 and larger: slower
+    E->tile4 = E->dense && (long long)((d.L + 63) / 64) * ((d.M + 7) / 8) <= 5000;
+    if (getenv("BEOM_TILE4")) E->tile4 = E->dense && atoi(getenv("BEOM_TILE4")) != 0;      // (A/B switch)
     if (E->lid) E->fuse = E->fuse_uv = E->fuse_muv = false;      // the lid's flux rebuild reads the stored d2hx, d2hy of the last layer
     d.edge_global = getenv("BEOM_EDGE_GLOBAL") != nullptr;
     E->wind = false;
@@ -744,22 +762,25 @@ static void launch_uv(beom_engine *E, int ilay, double gene, double ramp, double
     else LAUNCH_CTX((k_update_uv<CellGather, XDIR>), (k_update_uv<CellDense, XDIR>), nz, E->d, ilay, gene, ramp, ctim, copy_hist);
     if (!copy_hist) { if (XDIR) rot3(E->d.dmx); else rot3(E->d.dmy); }
 }
+#define TNS t8
+#define TSUF t8
+#include "beom_launch_tiled.h"
+#undef TNS
+#undef TSUF
+#define TNS t4
+#define TSUF t4
+#include "beom_launch_tiled.h"
+#undef TNS
+#undef TSUF
 // fused Montgomery + Leith sweep (dense frames); false if no instantiation for this nlay
 // leith: this step refreshes the Leith viscosity (:2188, :2268); else the sweep forms the products of the
 // standing v_cc, v_ll.  keep_visc: a refreshed viscosity has to stand for later steps (n_3d > 1).
 static bool launch_mont_visc(beom_engine *E, bool uv_fused_follows, bool leith, bool keep_visc) {
-    const dim3 g = mont_visc_grid(E->d), b(BEOM_BLOCK);
     E->d.lean_d2h = uv_fused_follows && E->lean_d2h && !E->d.keep_diag;
     E->d.keep_visc = keep_visc;
     E->d.zero_visc = !leith && uv_fused_follows && E->lean_visc && E->visc_all_zero && E->P.dvis == 0.0 && E->P.bvis == 0.0 &&
                      !E->d.keep_diag;
-    switch (E->d.nlay) {
-#define CASE_NL(n) case n: if (leith) hipLaunchKernelGGL((k_mont_visc<n, true>), g, b, 0, E->stream, E->d); \
-                           else hipLaunchKernelGGL((k_mont_visc<n, false>), g, b, 0, E->stream, E->d); return true;
-        CASE_NL(1) CASE_NL(2) CASE_NL(3) CASE_NL(4) CASE_NL(5) CASE_NL(6) CASE_NL(7) CASE_NL(8)
-#undef CASE_NL
-        default: return false;
-    }
+    return E->tile4 ? raw_mont_visc_t4(E, leith) : raw_mont_visc_t8(E, leith);
 }
 // fused U+V sweep (dense frames): first_x = update_u first (even tstp)
 static void uv_fused_swap(beom_engine *E, bool first_x) {
@@ -770,18 +791,9 @@ static void uv_fused_swap(beom_engine *E, bool first_x) {
 }
 static void launch_uv_fused(beom_engine *E, bool first_x, bool prod, double gene, double ramp, double ctim,
                             bool swap = true) {
-    const dim3 g = uv_fused_grid(E->d), b(UV_BLOCK);
-    DevView &d = E->d;
-    const bool zv = prod && d.zero_visc;          // set by launch_mont_visc of this step
-    if (first_x) {
-        if (zv) hipLaunchKernelGGL((k_uv_fused<true, true, true>), g, b, 0, E->stream, d, gene, ramp, ctim);
-        else if (prod) hipLaunchKernelGGL((k_uv_fused<true, true>), g, b, 0, E->stream, d, gene, ramp, ctim);
-        else hipLaunchKernelGGL((k_uv_fused<true, false>), g, b, 0, E->stream, d, gene, ramp, ctim);
-    } else {
-        if (zv) hipLaunchKernelGGL((k_uv_fused<false, true, true>), g, b, 0, E->stream, d, gene, ramp, ctim);
-        else if (prod) hipLaunchKernelGGL((k_uv_fused<false, true>), g, b, 0, E->stream, d, gene, ramp, ctim);
-        else hipLaunchKernelGGL((k_uv_fused<false, false>), g, b, 0, E->stream, d, gene, ramp, ctim);
-    }
+    const bool zv = prod && E->d.zero_visc;       // set by launch_mont_visc of this step
+    if (E->tile4) raw_uv_fused_t4(E, first_x, prod, zv, gene, ramp, ctim);
+    else raw_uv_fused_t8(E, first_x, prod, zv, gene, ramp, ctim);
     if (swap) uv_fused_swap(E, first_x);
 }
 // Montgomery + Leith + u + v as ONE sweep (k_muv) after the edge tiles' k_mont_visc; false if no instantiation
@@ -793,13 +805,9 @@ static bool launch_muv_edges(beom_engine *E, bool leith) {
     return ok;
 }
 static bool launch_muv(beom_engine *E, bool first_x, bool leith, double gene, double ramp, double ctim, bool swap = true) {
-    DevView &d = E->d;
-    const dim3 g = muv_grid(d), b(UV_BLOCK);
-    const bool zv = d.zero_visc;
-#define MUV_GO(fx, le, z) hipLaunchKernelGGL((k_muv<fx, le, z>), g, b, 0, E->stream, d, gene, ramp, ctim)
-    if (first_x) { if (leith) MUV_GO(true, true, false); else if (zv) MUV_GO(true, false, true); else MUV_GO(true, false, false); }
-    else         { if (leith) MUV_GO(false, true, false); else if (zv) MUV_GO(false, false, true); else MUV_GO(false, false, false); }
-#undef MUV_GO
+    const bool zv = E->d.zero_visc;
+    if (E->tile4) raw_muv_t4(E, first_x, leith, zv, gene, ramp, ctim);
+    else raw_muv_t8(E, first_x, leith, zv, gene, ramp, ctim);
     if (swap) uv_fused_swap(E, first_x);
     return true;
 }

@@ -7,8 +7,8 @@
 // Arithmetic follows the reference statement by statement and in its operation order
 // (compiled with -ffp-contract=off) so results are bit-identical to the Fortran.
 // HBM-bound FP64 stencils: no MFMA (nothing here is a contraction).
-#pragma once
-#include "beom_dev.h"
+// (no include guard: beom_engine.hip includes this file once per tile geometry, each time inside a namespace,
+//  after beom_dev.h; MV_Q and UV_WAVES select the geometry)
 
 #define LL(a, ip, il) (a)[(long long)(ip) + d.n1 * (long long)((il) - 1)]
 #define FNUD_(ip, il, iv) d.fnud[(long long)(ip) + d.n1 * ((long long)((il) - 1) + (long long)d.nlay * ((iv) - 1))]
@@ -278,12 +278,15 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_update_mont_all(DevView d) {
 #endif
 // tile of the fused u+v sweep (k_uv_fused, further down): k_mont_visc needs its geometry for lean_d2h
 #define UV_TX 64
-#define UV_Q 2
+#ifndef UV_Q
+#define UV_Q 2                         // rows (cells) per thread
+#endif
 #ifndef UV_WAVES
 #define UV_WAVES 4                     // waves (rows of 64 cells) per workgroup
 #endif
 #define UV_BLOCK (64 * UV_WAVES)
 #define UV_TY (UV_WAVES * UV_Q)
+static constexpr int kUvBlock = UV_BLOCK;      // (for the launch code: the macros hold the LAST geometry included)
 // tile (x0, y0) and everything its fused evaluation reads (3 cells around it) inside the wet interior
 __device__ __forceinline__ bool muv_tile_interior(const DevView &d, int x0, int y0) {
     return x0 - 2 >= 2 && x0 + UV_TX + 1 <= d.L - 2 && y0 - 2 >= 2 && y0 + UV_TY + 1 <= d.M - 2
