@@ -203,6 +203,7 @@ def main():
     p = recipe.p
     n_gpus = a.gpus
     halo = None
+    rccl_failed = None
     banded = n_gpus > 1 or a.force_bands
     if not banded:
         f = read_input_data(p, files=recipe.rows(0, p.mm + 1))
@@ -216,13 +217,50 @@ def main():
         dense = True
         reset = lambda: eng.upload(**{k: getattr(f, k) for k in capi.STATE_NAMES})
     else:
-        uid = [capi.rccl_unique_id() if rank == 0 else None]
+        why = None
+        eng = None
+        try:
+            uid = [capi.rccl_unique_id() if rank == 0 else None]
+        except capi.BeomError as exc:                                    # librccl could not be bound on this machine
+            uid, why = [b""], str(exc)
         if world > 1:
             dist.broadcast_object_list(uid, src=0)
-        f, geom, orphan = slab.build_band(recipe, world, rank)           # this rank's rows only
-        eng = capi.BandEngine(f, p, world, rank, device=local_rank, rccl_id=uid[0], orphan=orphan)
+        if uid[0]:
+            try:
+                f, geom, orphan = slab.build_band(recipe, world, rank)   # this rank's rows only
+                eng = capi.BandEngine(f, p, world, rank, device=local_rank, rccl_id=uid[0], orphan=orphan)
+            except capi.BeomError as exc:
+                why = str(exc)
+        ok = eng is not None
+        if world > 1:
+            t = torch.tensor([1 if ok else 0])
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            ok = bool(t.item())
+        if not ok:
+            # No RCCL communicator on this machine.  Rather than no measurement at all: ONE process (rank 0) drives the N
+            # devices with peer copies (the other transport of the same library loop); config.halo says so, with the reason.
+            reasons = [why]
+            if world > 1:
+                reasons = [None] * world
+                dist.all_gather_object(reasons, why)
+            if eng is not None:
+                eng.close()
+            if world > 1:
+                dist.barrier()
+                dist.destroy_process_group()
+            if rank != 0:
+                os.dup2(real_stdout, 1)
+                sys.exit(0)
+            world = 1
+            rccl_failed = "; ".join(sorted({str(r)[:300] for r in reasons if r})) or "unknown"
+            print("bench.py: RCCL transport unavailable (%s): one process, peer copies" % rccl_failed, file=sys.stderr)
+            a.single_process, a.transport = True, "peer"
+            f = read_input_data(p, files=recipe.rows(0, p.mm + 1))
+            eng = capi.MultiEngine(f, devices=[d % ndev for d in range(n_gpus)], transport=capi.XCHG_PEER)
+            reset = lambda: eng.upload(**{k: getattr(f, k) for k in capi.STATE_NAMES})
+        else:
+            reset = lambda: eng.upload()
         dense = True
-        reset = lambda: eng.upload()
     if banded:
         d = eng.describe()
         L = p.lm + 1
@@ -239,6 +277,8 @@ def main():
                 "fields": list(slab.EXCHANGED), "bytes_per_direction_per_step": len(slab.EXCHANGED) * p.nlay * slab.GHOST * L * 8,
                 "step_loop": "inside the library (beom_multi_step)", "state_build": "global arrays, cut by the library"
                 if a.single_process else "each rank builds its own rows from the recipe"}
+        if rccl_failed:
+            halo["fallback"] = "RCCL transport unavailable (%s): ONE process drives the %d devices over peer copies" % (rccl_failed, n_gpus)
     t_setup = time.time() - t0
 
     def barrier():

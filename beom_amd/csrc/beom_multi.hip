@@ -77,6 +77,7 @@ struct Rccl {
     int (*GetVersion)(int *) = nullptr;
     bool load(char *errm, int errm_len) {
         if (lib) return true;
+        if (getenv("BEOM_RCCL_DISABLE")) { m_err(errm, errm_len, "RCCL switched off by BEOM_RCCL_DISABLE (rehearsal of a machine without it)"); return false; }
         const char *names[] = {getenv("BEOM_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         for (const char *nm : names) {
             if (!nm || !*nm) continue;
