@@ -53,6 +53,7 @@ void set_err(char *errm, int len, const char *fmt, ...) {
 struct StepTimer {        // optional HIP-event bracket around each kernel class
     std::vector<hipEvent_t> ev; std::vector<int> cls;
     hipStream_t st;
+    int stride = 1;       // only the steps with tstp % stride == 0 are bracketed (an event pair costs a few us of pipeline bubble)
     void begin(int c) { hipEvent_t a; (void)hipEventCreate(&a); (void)hipEventRecord(a, st); ev.push_back(a); cls.push_back(c); }
     void end() { hipEvent_t b; (void)hipEventCreate(&b); (void)hipEventRecord(b, st); ev.push_back(b); }
 };
@@ -98,6 +99,7 @@ struct beom_engine {
     // rigid lid (rgld = 1): the caller's subc and the packed -> device index map, kept for beom_set_rigid_lid
     std::vector<int32_t> subc_host, neig_host, dev_index;
     bool lid = false, lid_ready = false;
+    int profile_stride = 1;            // option "profile_stride"
     bool tile4 = false;                // the tiled sweeps run the 64 x 4 geometry (frames of one or two rounds of workgroups)
     char last_err[512] = {0};
 };
@@ -889,7 +891,7 @@ static StepScalars step_scalars(const beom_engine *E, int tstp, double tres, dou
 }
 
 static void one_step(beom_engine *E, int tstp, const StepScalars &s) {
-    StepTimer *T = E->timer;
+    StepTimer *T = (E->timer && tstp % E->timer->stride == 0) ? E->timer : nullptr;
     if (T) T->st = E->stream;
     if (s.stress) launch_stress(E);
     if (E->lid) launch_lid_fluxes(E, s.first3);
@@ -1020,6 +1022,7 @@ int beom_profile_start(beom_handle E) {
     if (E->timer) { for (hipEvent_t ev : E->timer->ev) (void)hipEventDestroy(ev); delete E->timer; }
     E->timer = new StepTimer();
     E->timer->st = E->stream;
+    E->timer->stride = E->profile_stride;
     return 0;
 }
 
@@ -1079,7 +1082,7 @@ int beom_step_phase(beom_handle E, int tstp, double tres, double dtd8, double dt
     }
     const int M = d.M;
     const bool u_first = tstp % 2 == 0;
-    StepTimer *T = E->timer;
+    StepTimer *T = (E->timer && tstp % E->timer->stride == 0) ? E->timer : nullptr;
     if (T) T->st = E->stream;
     if (phase == 1) {
         set_rows(d, 1, south ? 9 : 1, north ? M - 8 : M);
@@ -1303,6 +1306,7 @@ int beom_set_option(beom_handle E, const char *name, int value) {
     else if (!strcmp(name, "fuse_muv")) E->fuse_muv = value != 0 && !E->lid;
     else if (!strcmp(name, "graph")) E->use_graph = value;
     else if (!strcmp(name, "keep_diag")) E->d.keep_diag = value != 0;
+    else if (!strcmp(name, "profile_stride")) E->profile_stride = value > 0 ? value : 1;
     else if (!strcmp(name, "lean_d2h")) E->lean_d2h = value != 0;
     else if (!strcmp(name, "lean_visc")) E->lean_visc = value != 0;
     else return -3;

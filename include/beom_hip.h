@@ -204,6 +204,9 @@ int beom_unpack_rows(beom_handle h, int jlo, int nrows, const void *device_buffe
  *      replayed from HIP graphs, each holding one full period of the pointer rotations; -1 = only for dense frames of at
  *      most 4 M cell-layers.  Measured on the soliton (2048x256) and Stommel (128x128) frames: no gain over individual
  *      launches (the sweeps of such frames are bound by their own dependent memory round trips), hence off by default.
+ *  "profile_stride" (default 1): beom_profile_start brackets only the steps with tstp % stride == 0 with HIP events
+ *      (an event pair between two launches costs a few microseconds of pipeline bubble: sampled, the timed region is
+ *      hardly disturbed; the launch counts beom_profile_stop returns are those of the sampled steps).
  * Returns -3 for an unknown name. */
 int beom_set_option(beom_handle h, const char *name, int value);
 /* how many time steps of this handle ran from HIP graphs / as individual launches */

@@ -500,6 +500,12 @@ def test_profile_start_stop_counts_launches():
     e.step(17, 4, sync=False)
     ms, nl = e.profile_stop()
     assert nl == [4, 4, 4, 4, 4, 0, 0, 0] and all(m > 0 for m in ms[:5])
+    e.set_option("fuse", 1)
+    e.set_option("profile_stride", 4)        # only the steps with tstp % 4 == 0 are bracketed: 24 and 28 of 21..30
+    e.profile_start()
+    e.step(21, 10, sync=False)
+    ms, nl = e.profile_stop()
+    assert nl == [2, 0, 0, 0, 0, 2, 2, 0]
     e.close()
 
 
