@@ -16,6 +16,9 @@ def _case():
             "headline": lambda: I.case_headline(4096, 4096, 4),
             "headline_gather": lambda: I.case_headline(4096, 4096, 4),     # same frame through the neig tables
             "headline_land": lambda: with_land(I.case_headline(4096, 4096, 4)),
+            "band8": lambda: I.case_headline(4096, 512, 4),                # what one of 8 / 4 / 2 bands of the headline frame holds
+            "band4": lambda: I.case_headline(4096, 1024, 4),
+            "band2": lambda: I.case_headline(4096, 2048, 4),
             "closed_small": lambda: I.case_headline(2048, 256, 1),         # the soliton's frame as a closed basin (no periodic seam)
             "closed_small4": lambda: I.case_headline(1024, 128, 4),        # the same number of cell-layers in 4 layers
             }[case]()
