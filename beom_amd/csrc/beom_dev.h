@@ -82,17 +82,20 @@ struct DevView {
     int has_hdot, has_tide, has_bodf, has_nudg, has_stress, has_wind, has_hto;
 };
 
-// ---- tile rows of the selected strips --------------------------------------------------
-// A launch covers the tile rows (TY rows each) that intersect the strips; workgroups are dealt
-// to the 8 XCDs in bands of those tile rows (MI355X_MICROARCH.md: consecutive workgroups go
-// round-robin to the XCDs), so each XCD sweeps its own rows and its L2 keeps the neighbours.
-// Within its band an XCD sweeps whole tile rows, x fastest: HBM wants the long contiguous row streams (strips a few tiles
-// wide, which would keep the halo rows in L2, made every sweep slower: profiles/r02_ab_experiments.txt).  The tiles on the
-// frame's rim take the general paths (masks, wraps) and live longer than interior ones, so they are handed out FIRST — the
-// rim columns at the head of every tile row, the top rim row at the head of the last XCD's band — and do not form the tail
-// of a launch; done for launches of at most 4096 tiles, which are mostly tail (soliton 2048 x 256: -3 %).
+// ---- tiles of the selected strips --------------------------------------------------------
+// A launch covers the tile rows (TY rows each) that intersect the strips.  Consecutive workgroups go round-robin to the 8
+// XCDs (MI355X_MICROARCH.md), so workgroup b serves XCD b & 7, and each XCD gets one contiguous band of the tile rows (its
+// L2 keeps the neighbours), swept x fastest: HBM wants the long contiguous row streams (strips a few tiles wide, which
+// would keep the halo rows in L2, made every sweep slower: profiles/r02_ab_experiments.txt).
+//  * Whole tile rows per XCD leave the last XCD short: 65 tile rows are 9 + ... + 9 + 2 and the launch lasts as long as the
+//    XCDs with 9 (+11 %).  Where that costs more than 3 % on a launch of several rounds, the bands are cut to the tile
+//    instead (an eighth of the tiles in row-major order each): 4096 x 512 x 4 -3 %, 4096 x 1024 x 4 -2 %.  (Frames whose
+//    rows divide well keep whole rows: cutting mid-row cost 4096^2 x 4 +0.9 %.)
+//  * The tiles on the frame's rim take the general paths (masks, wraps) and live longer than interior ones, so on launches
+//    of at most 4096 tiles — which are mostly tail — they are handed out FIRST: the rim columns at the head of every
+//    tile row, the top rim row at the head of the last XCD's band (soliton 2048 x 256: -3 %).
 struct TileMap {
-    int tr0a, ntra, tr0b, ntrb, total, rpx, gx, xlast, nlast, rim_first;
+    int tr0a, ntra, tr0b, ntrb, total, gx, rpx, tpx, nt, xlast, nlast, rim_first, by_tiles;
     // forceinline: an out-of-line call would take the address of the kernel argument and push all
     // of DevView (~1 KB per lane) into scratch memory
     __host__ __device__ __forceinline__ TileMap(const DevView &d, int TX, int TY) {
@@ -101,24 +104,34 @@ struct TileMap {
         if (d.jhi0 >= d.jlo0) { tr0a = (d.jlo0 - 1) / TY; ntra = (d.jhi0 - 1) / TY - tr0a + 1; }
         if (d.nstrip > 1 && d.jhi1 >= d.jlo1) { tr0b = (d.jlo1 - 1) / TY; ntrb = (d.jhi1 - 1) / TY - tr0b + 1; }
         total = ntra + ntrb;
-        rpx = (total + 7) / 8;
-        xlast = total > 0 ? (total - 1) / rpx : 0;          // the last XCD that has tile rows, and how many
+        nt = total * gx;                                    // tiles of the launch
+        rpx = (total + 7) / 8;                              // tile rows per XCD
+        rim_first = nt <= 4096;
+        by_tiles = !rim_first && (rpx * 8 - total) * 100 > 3 * total;
+        tpx = by_tiles ? (nt + 7) / 8 : rpx * gx;           // workgroups per XCD
+        xlast = total > 0 ? (total - 1) / rpx : 0;          // (whole rows) the last XCD that has tile rows, and how many
         nlast = total - xlast * rpx;
-        rim_first = (long long)gx * total <= 4096;          // (a launch of many rounds has no tail to speak of: plain order, +0.3 % there)
     }
-    __host__ unsigned blocks() const { return (unsigned)(8 * rpx * gx); }
+    __host__ unsigned blocks() const { return (unsigned)(8 * tpx); }
     // blockIdx.x -> tile row (absolute) and column chunk; false if this workgroup has no tile
     __device__ __forceinline__ bool locate(int b, int &ty, int &ch) const {
         const int xcd = b & 7, k = b >> 3;
-        int rib = k / gx;
-        const int c = k - rib * gx;
-        ch = c;
-        if (rim_first) {
-            ch = c == 0 ? 0 : (c == 1 ? gx - 1 : c - 1);              // rim columns first
-            if (xcd == xlast && rib < nlast) rib = nlast - 1 - rib;    // the top band top-down
+        int vt;
+        if (by_tiles) {
+            const int v = xcd * tpx + k;
+            if (v >= nt) return false;
+            vt = v / gx; ch = v - vt * gx;
+        } else {
+            int rib = k / gx;
+            const int c = k - rib * gx;
+            ch = c;
+            if (rim_first) {
+                ch = c == 0 ? 0 : (c == 1 ? gx - 1 : c - 1);              // rim columns first
+                if (xcd == xlast && rib < nlast) rib = nlast - 1 - rib;    // the top band top-down
+            }
+            vt = xcd * rpx + rib;
+            if (rib >= rpx || vt >= total) return false;
         }
-        const int vt = xcd * rpx + rib;
-        if (rib >= rpx || vt >= total) return false;
         ty = vt < ntra ? tr0a + vt : tr0b + (vt - ntra);
         return true;
     }
