@@ -100,6 +100,7 @@ struct beom_engine {
     std::vector<int32_t> subc_host, neig_host, dev_index;
     bool lid = false, lid_ready = false;
     int profile_stride = 1;            // option "profile_stride"
+    hipEvent_t ev_h1 = nullptr, ev_mv1 = nullptr;   // split steps: phase 1 has run update_h / the Montgomery sweep (phase 2 may be on another stream)
     bool tile4 = false;                // the tiled sweeps run the 64 x 4 geometry (frames of one or two rounds of workgroups)
     char last_err[512] = {0};
 };
@@ -473,6 +474,7 @@ int beom_destroy(beom_handle E) {
     graphs_clear(E);
     for (void *p : E->allocs) (void)hipFree(p);
     if (E->stage) (void)hipFree(E->stage);
+    for (hipEvent_t ev : {E->ev_h1, E->ev_mv1}) if (ev) (void)hipEventDestroy(ev);
     if (E->timer) { for (hipEvent_t ev : E->timer->ev) (void)hipEventDestroy(ev); delete E->timer; }
     if (E->own_stream) (void)hipStreamDestroy(E->own_stream);
     delete E;
@@ -1084,15 +1086,22 @@ int beom_step_phase(beom_handle E, int tstp, double tres, double dtd8, double dt
     const bool u_first = tstp % 2 == 0;
     StepTimer *T = (E->timer && tstp % E->timer->stride == 0) ? E->timer : nullptr;
     if (T) T->st = E->stream;
+    // Phase 2 may be enqueued on ANOTHER stream than phase 1 (beom_multi: the edge strips then run inside the interior
+    // sweeps instead of after them).  Its sweeps read what phase 1's sweep of the kind before wrote next to the strips
+    // (Montgomery of rows 1..9 reads the thickness of row 10; the momentum sweep of rows 1..10 the potentials of row 11):
+    // two events say when.  Phase 1 reads nothing phase 2 writes.
+    if (!E->ev_h1) { HIP_TRY(hipEventCreateWithFlags(&E->ev_h1, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&E->ev_mv1, hipEventDisableTiming)); }
     if (phase == 1) {
         set_rows(d, 1, south ? 9 : 1, north ? M - 8 : M);
         if (T) T->begin(0);
         launch_h(E, s.gene, s.ramp, s.ctim, false);
         if (T) T->end();
+        HIP_TRY(hipEventRecord(E->ev_h1, E->stream));
         if (s.muv) {
             if (T) T->begin(5);
             set_rows(d, 1, south ? 10 : 1, north ? M - 9 : M);
             launch_muv_edges(E, E->P.dvis > 1.e-3 && s.upst);
+            HIP_TRY(hipEventRecord(E->ev_mv1, E->stream));
             if (T) { T->end(); T->begin(7); }
             set_rows(d, 1, south ? 11 : 1, north ? M - 10 : M);
             launch_muv(E, u_first, E->P.dvis > 1.e-3 && s.upst, s.gene, s.ramp, s.ctim, false);
@@ -1101,6 +1110,7 @@ int beom_step_phase(beom_handle E, int tstp, double tres, double dtd8, double dt
             if (T) T->begin(s.fused ? 5 : 1);
             set_rows(d, 1, south ? 10 : 1, north ? M - 9 : M);
             if (s.fused) launch_mont_visc(E, true, E->P.dvis > 1.e-3 && s.upst, E->P.dvis > 1.e-3 && s.upst && s.n_3d > 1); else launch_mont(E, 0);
+            HIP_TRY(hipEventRecord(E->ev_mv1, E->stream));
             if (T) { T->end(); T->begin(6); }
             set_rows(d, 1, south ? 11 : 1, north ? M - 10 : M);
             launch_uv_fused(E, u_first, s.fused, s.gene, s.ramp, s.ctim, false);
@@ -1117,10 +1127,12 @@ int beom_step_phase(beom_handle E, int tstp, double tres, double dtd8, double dt
         if (T) T->begin(0);
         launch_h(E, s.gene, s.ramp, s.ctim, true);
         if (T) T->end();
+        HIP_TRY(hipStreamWaitEvent(E->stream, E->ev_h1, 0));
         if (s.muv) {
             if (T) T->begin(5);
             strips(9);
             launch_muv_edges(E, E->P.dvis > 1.e-3 && s.upst);
+            HIP_TRY(hipStreamWaitEvent(E->stream, E->ev_mv1, 0));
             if (T) { T->end(); T->begin(7); }
             strips(10);
             launch_muv(E, u_first, E->P.dvis > 1.e-3 && s.upst, s.gene, s.ramp, s.ctim, true);
@@ -1129,6 +1141,7 @@ int beom_step_phase(beom_handle E, int tstp, double tres, double dtd8, double dt
             if (T) T->begin(s.fused ? 5 : 1);
             strips(9);
             if (s.fused) launch_mont_visc(E, true, E->P.dvis > 1.e-3 && s.upst, E->P.dvis > 1.e-3 && s.upst && s.n_3d > 1); else launch_mont(E, 0);
+            HIP_TRY(hipStreamWaitEvent(E->stream, E->ev_mv1, 0));
             if (T) { T->end(); T->begin(6); }
             strips(10);
             launch_uv_fused(E, u_first, s.fused, s.gene, s.ramp, s.ctim, true);

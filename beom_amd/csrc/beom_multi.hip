@@ -222,14 +222,15 @@ struct beom_multi {
     bool local_mode = false;       // created from this band's window (beom_multi_create_local)
     bool failed = false;           // a step failed half way: the state is undefined, only destroy is allowed
     bool overlap = true;           // split steps around the exchange in flight (beom_multi_set_option "overlap")
+    bool edge_stream = true;       // ... with the edge strips on a stream of their own, inside the interior sweeps ("edge_stream")
     size_t n1g = 0;
     bool land = false;             // a frame with land: bands are packed row ranges of unequal length, on the rectangle ("embedded") form
     std::vector<long long> gst;    // land: first packed cell of every global row j = 1..mm+2
     std::vector<int> dev;
     std::vector<Band> band;
     std::vector<beom_handle> eng;
-    std::vector<hipStream_t> main_s, comm_s;
-    std::vector<hipEvent_t> packed, landed;
+    std::vector<hipStream_t> main_s, comm_s, edge_s;   // a band's sweeps | its exchange | the edge strips of its split steps
+    std::vector<hipEvent_t> packed, landed, p1start, p2done;
     std::vector<char> pending;     // an exchange into this band is in flight
     std::vector<double *> send_s, recv_s, send_n, recv_n;   // device buffers on the band's device
     std::vector<nccl_comm> comm;
@@ -259,6 +260,7 @@ void destroy_all(beom_multi *M) {
         (void)hipSetDevice(M->dev[k]);
         if (k < (int)M->main_s.size() && M->main_s[k]) (void)hipStreamSynchronize(M->main_s[k]);
         if (k < (int)M->comm_s.size() && M->comm_s[k]) (void)hipStreamSynchronize(M->comm_s[k]);
+        if (k < (int)M->edge_s.size() && M->edge_s[k]) (void)hipStreamSynchronize(M->edge_s[k]);
     }
     if (M->mini_k >= 0) {
         (void)hipSetDevice(M->dev[M->mini_k]);
@@ -277,6 +279,9 @@ void destroy_all(beom_multi *M) {
             if (k < (int)v->size() && (*v)[k]) (void)hipFree((*v)[k]);
         if (k < (int)M->packed.size() && M->packed[k]) (void)hipEventDestroy(M->packed[k]);
         if (k < (int)M->landed.size() && M->landed[k]) (void)hipEventDestroy(M->landed[k]);
+        if (k < (int)M->p1start.size() && M->p1start[k]) (void)hipEventDestroy(M->p1start[k]);
+        if (k < (int)M->p2done.size() && M->p2done[k]) (void)hipEventDestroy(M->p2done[k]);
+        if (k < (int)M->edge_s.size() && M->edge_s[k]) (void)hipStreamDestroy(M->edge_s[k]);
         if (k < (int)M->comm_s.size() && M->comm_s[k]) (void)hipStreamDestroy(M->comm_s[k]);
         if (k < (int)M->main_s.size() && M->main_s[k]) (void)hipStreamDestroy(M->main_s[k]);
     }
@@ -394,8 +399,11 @@ int finish_band(beom_multi *M, int k, char *errm, int errm_len) {
     M_HIP(hipSetDevice(M->dev[k]));
     M_HIP(hipStreamCreateWithFlags(&M->main_s[k], hipStreamNonBlocking));
     M_HIP(hipStreamCreateWithFlags(&M->comm_s[k], hipStreamNonBlocking));
+    M_HIP(hipStreamCreateWithFlags(&M->edge_s[k], hipStreamNonBlocking));
     M_HIP(hipEventCreateWithFlags(&M->packed[k], hipEventDisableTiming));
     M_HIP(hipEventCreateWithFlags(&M->landed[k], hipEventDisableTiming));
+    M_HIP(hipEventCreateWithFlags(&M->p1start[k], hipEventDisableTiming));
+    M_HIP(hipEventCreateWithFlags(&M->p2done[k], hipEventDisableTiming));
     if (M->has_s(k)) { M_HIP(hipMalloc((void **)&M->send_s[k], M->xbytes)); M_HIP(hipMalloc((void **)&M->recv_s[k], M->xbytes)); }
     if (M->has_n(k)) { M_HIP(hipMalloc((void **)&M->send_n[k], M->xbytes)); M_HIP(hipMalloc((void **)&M->recv_n[k], M->xbytes)); }
     (void)beom_set_stream(M->eng[k], (void *)M->main_s[k], 0);
@@ -462,8 +470,8 @@ int init_transport(beom_multi *M, const void *rccl_id, char *errm, int errm_len)
 void size_vectors(beom_multi *M) {
     const int n = M->n;
     M->eng.assign(n, nullptr);
-    M->main_s.assign(n, nullptr); M->comm_s.assign(n, nullptr);
-    M->packed.assign(n, nullptr); M->landed.assign(n, nullptr);
+    M->main_s.assign(n, nullptr); M->comm_s.assign(n, nullptr); M->edge_s.assign(n, nullptr);
+    M->packed.assign(n, nullptr); M->landed.assign(n, nullptr); M->p1start.assign(n, nullptr); M->p2done.assign(n, nullptr);
     M->pending.assign(n, 0);
     M->send_s.assign(n, nullptr); M->recv_s.assign(n, nullptr);
     M->send_n.assign(n, nullptr); M->recv_n.assign(n, nullptr);
@@ -736,6 +744,7 @@ int beom_multi_stats(beom_multi_handle M, long long *split_band_steps, long long
 int beom_multi_set_option(beom_multi_handle M, const char *name, int value) {
     if (!M || !name) return -1;
     if (!strcmp(name, "overlap")) { M->overlap = value != 0; return 0; }
+    if (!strcmp(name, "edge_stream")) { M->edge_stream = value != 0; return 0; }
     int rc = 0;
     for (int k = 0; k < M->n && !rc; ++k) rc = beom_set_option(M->eng[k], name, value);
     if (!rc && M->mini) rc = beom_set_option(M->mini, name, value);
@@ -758,6 +767,7 @@ int beom_multi_sync(beom_multi_handle M, char *errm, int errm_len) {
         M_HIP(hipSetDevice(M->dev[k]));
         M_HIP(hipStreamSynchronize(M->main_s[k]));
         if (M->comm_s[k]) M_HIP(hipStreamSynchronize(M->comm_s[k]));
+        if (M->edge_s[k]) M_HIP(hipStreamSynchronize(M->edge_s[k]));
         M->pending[k] = 0;          // whatever was in flight has landed
     }
     if (M->mini) { M_HIP(hipSetDevice(M->dev[M->mini_k])); M_HIP(hipStreamSynchronize(M->mini_s)); }
@@ -1061,6 +1071,8 @@ static int multi_one_step(beom_multi *M, int t, double tres, double dtd8, double
     // phase 1: the rows that cannot depend on the ghosts still in flight
     for (int k = 0; k < n; ++k) {
         if (!M->pending[k] || !M->overlap) continue;
+        M_HIP(hipSetDevice(M->dev[k]));
+        M_HIP(hipEventRecord(M->p1start[k], M->main_s[k]));       // everything of the previous step is ahead of this point
         const int rc = beom_step_phase(M->eng[k], t, tres, dtd8, dt_r, rsta, n_3d, 1, errm, errm_len);
         if (rc == 0) split[k] = 1;
         else if (rc != -20) return rc;
@@ -1069,12 +1081,18 @@ static int multi_one_step(beom_multi *M, int t, double tres, double dtd8, double
     // neighbours': before I overwrite the send buffers they copy from)
     for (int k = 0; k < n; ++k) {
         M_HIP(hipSetDevice(M->dev[k]));
-        if (M->pending[k]) M_HIP(hipStreamWaitEvent(M->main_s[k], M->landed[k], 0));
-        if (M->transport == BEOM_XCHG_PEER)
-            for (int q : {M->south_of(k), M->north_of(k)}) {
-                const int ql = M->local_of(q);
-                if (ql >= 0 && ql != k && M->pending[ql]) M_HIP(hipStreamWaitEvent(M->main_s[k], M->landed[ql], 0));
-            }
+        // a split band's edge strips go to the band's edge stream: behind the previous step (p1start), behind the ghosts
+        hipStream_t both[2] = {M->main_s[k], (split[k] && M->edge_stream) ? M->edge_s[k] : nullptr};
+        if (both[1]) M_HIP(hipStreamWaitEvent(both[1], M->p1start[k], 0));
+        for (hipStream_t st : both) {
+            if (!st) continue;
+            if (M->pending[k]) M_HIP(hipStreamWaitEvent(st, M->landed[k], 0));
+            if (M->transport == BEOM_XCHG_PEER)
+                for (int q : {M->south_of(k), M->north_of(k)}) {
+                    const int ql = M->local_of(q);
+                    if (ql >= 0 && ql != k && M->pending[ql]) M_HIP(hipStreamWaitEvent(st, M->landed[ql], 0));
+                }
+        }
     }
     for (int k = 0; k < n; ++k) M->pending[k] = 0;
     // companion frame: band 0's south ghosts (rows mm-3..mm) are fresh now -> refresh, then its step
@@ -1095,7 +1113,18 @@ static int multi_one_step(beom_multi *M, int t, double tres, double dtd8, double
     // the rest of the step, then pack what the neighbours need = my outermost OWNED rows
     for (int k = 0; k < n; ++k) {
         const Band &s = M->band[k];
-        if (split[k]) { M_RC(beom_step_phase(M->eng[k], t, tres, dtd8, dt_r, rsta, n_3d, 2, errm, errm_len)); ++M->n_split; }
+        if (split[k] && M->edge_stream) {
+            // the strips next to the ghost zones: three small launches that would otherwise FOLLOW the interior sweeps run
+            // inside them (each waits for the interior sweep before it, beom_step_phase); the band's stream goes on after them
+            M_HIP(hipSetDevice(M->dev[k]));
+            struct Back { beom_multi *M; int k; ~Back() { (void)beom_set_stream(M->eng[k], (void *)M->main_s[k], 0); } } back{M, k};
+            (void)beom_set_stream(M->eng[k], (void *)M->edge_s[k], 0);
+            if (M->mini && k == mk) M_HIP(hipStreamWaitEvent(M->edge_s[k], M->ev_hi, 0));   // (the companion frame's copy of the ghost rows is taken first)
+            M_RC(beom_step_phase(M->eng[k], t, tres, dtd8, dt_r, rsta, n_3d, 2, errm, errm_len));
+            M_HIP(hipEventRecord(M->p2done[k], M->edge_s[k]));
+            M_HIP(hipStreamWaitEvent(M->main_s[k], M->p2done[k], 0));
+            ++M->n_split;
+        } else if (split[k]) { M_RC(beom_step_phase(M->eng[k], t, tres, dtd8, dt_r, rsta, n_3d, 2, errm, errm_len)); ++M->n_split; }
         else { M_RC(beom_step(M->eng[k], t, 1, tres, dtd8, dt_r, rsta, n_3d, errm, errm_len)); ++M->n_plain; }
         if (M->has_s(k) && beom_pack_rows(M->eng[k], s.gs + 1, kGhost, M->send_s[k])) { m_err(errm, errm_len, "beom_pack_rows failed"); return -3; }
         if (M->has_n(k) && beom_pack_rows(M->eng[k], s.gs + s.nown() - kGhost + 1, kGhost, M->send_n[k])) { m_err(errm, errm_len, "beom_pack_rows failed"); return -3; }
