@@ -277,6 +277,9 @@ def main():
                 "fields": list(slab.EXCHANGED), "bytes_per_direction_per_step": len(slab.EXCHANGED) * p.nlay * slab.GHOST * L * 8,
                 "step_loop": "inside the library (beom_multi_step)", "state_build": "global arrays, cut by the library"
                 if a.single_process else "each rank builds its own rows from the recipe"}
+        halo["per_kernel_note"] = ("a split step launches every sweep twice (interior rows, then the strips next to the ghost zones on a "
+                                   "stream of their own INSIDE the interior sweeps): roofline.per_kernel sums both, so concurrent time "
+                                   "is counted twice there; `value` is wall time")
         if rccl_failed:
             halo["fallback"] = "RCCL transport unavailable (%s): ONE process drives the %d devices over peer copies" % (rccl_failed, n_gpus)
     t_setup = time.time() - t0
