@@ -48,7 +48,7 @@ class BeomState(C.Structure):
                                                      "v_cc", "v_ll", "tt3d", "tb3d", "tu3d")]
 
 
-XCHG_PEER, XCHG_RCCL, XCHG_RING1 = 0, 1, 0x100
+XCHG_PEER, XCHG_RCCL, XCHG_SHM, XCHG_RING1, XCHG_LOOPBACK = 0, 1, 2, 0x100, 0x200
 
 
 def make_params_struct(p: Params, f: Optional[Fields] = None, variant: int = 0,
@@ -188,6 +188,8 @@ def load(path: Optional[str] = None) -> C.CDLL:
     lib.beom_multi_window.argtypes = [C.POINTER(BeomParams), ci, ci, ci] + [C.POINTER(ci)] * 4
     lib.beom_multi_create_local.argtypes = [C.POINTER(BeomParams), ci, ci, ci, ci, ci, C.c_void_p,
                                             C.POINTER(BeomStatics), C.POINTER(BeomStatics), C.POINTER(MH), cp, ci]
+    lib.beom_multi_create_local_ex.argtypes = [C.POINTER(BeomParams), ci, ci, ci, ci, ci, ci, C.c_void_p,
+                                               C.POINTER(BeomStatics), C.POINTER(BeomStatics), C.POINTER(MH), cp, ci]
     lib.beom_multi_upload_local.argtypes = [MH, C.POINTER(BeomState), C.POINTER(BeomState), cp, ci]
     lib.beom_multi_download_local.argtypes = [MH, C.POINTER(BeomState), C.POINTER(BeomState), cp, ci]
     for name in ("beom_multi_create", "beom_multi_destroy", "beom_multi_count", "beom_multi_band",
@@ -195,7 +197,7 @@ def load(path: Optional[str] = None) -> C.CDLL:
                  "beom_multi_stats", "beom_multi_create_ex", "beom_multi_describe", "beom_multi_engine",
                  "beom_multi_download_outputs", "beom_multi_download_diag", "beom_multi_set_open_boundaries",
                  "beom_multi_set_option", "beom_multi_profile_start", "beom_multi_profile_stop", "beom_rccl_unique_id", "beom_rccl_version",
-                 "beom_multi_window", "beom_multi_create_local", "beom_multi_upload_local", "beom_multi_download_local"):
+                 "beom_multi_window", "beom_multi_create_local", "beom_multi_create_local_ex", "beom_multi_upload_local", "beom_multi_download_local"):
         getattr(lib, name).restype = ci
     for name in ("beom_device_count", "beom_create", "beom_destroy", "beom_upload_state",
                  "beom_download_state", "beom_download_scratch", "beom_step", "beom_sync",
@@ -224,7 +226,7 @@ EXPORTS = ("beom_abi_version", "beom_device_count", "beom_device_pci_bus_id", "b
            "beom_multi_stats", "beom_multi_create_ex", "beom_multi_describe", "beom_multi_engine",
            "beom_multi_download_outputs", "beom_multi_download_diag", "beom_multi_set_open_boundaries",
            "beom_multi_set_option", "beom_multi_profile_start", "beom_multi_profile_stop", "beom_rccl_unique_id", "beom_rccl_version",
-           "beom_multi_window", "beom_multi_create_local", "beom_multi_upload_local", "beom_multi_download_local")
+           "beom_multi_window", "beom_multi_create_local", "beom_multi_create_local_ex", "beom_multi_upload_local", "beom_multi_download_local")
 
 STATE_NAMES = ("hlay", "u", "v", "h_u", "h_v", "rs_h", "dmdx", "dmdy", "v_cc", "v_ll",
                "tt3d", "tb3d", "tu3d")
@@ -307,8 +309,9 @@ class Engine:
                                                    self._err, ERRLEN))
         return out
 
-    def step(self, tstp_first: int, nsteps: int, tres: float = 0.0, sync: bool = True):
+    def step(self, tstp_first: int, nsteps: int, tres: Optional[float] = None, sync: bool = True):
         p = self.p
+        tres = float(getattr(self.f, "tres", 0.0)) if tres is None else tres      # a restarted run continues from its record's time
         self._check(self.lib.beom_step(self.h, tstp_first, nsteps, tres, float(p.dtd8),
                                        float(p.dt_r), float(p.rsta), p.n_3d, self._err, ERRLEN))
         if sync:
@@ -325,9 +328,10 @@ class Engine:
         else:
             self._check(self.lib.beom_set_stream(self.h, C.c_void_p(hip_stream), 0))
 
-    def step_phase(self, tstp: int, phase: int, tres: float = 0.0) -> bool:
+    def step_phase(self, tstp: int, phase: int, tres: Optional[float] = None) -> bool:
         """Split step (beom_step_phase).  False if not available for this step."""
         p = self.p
+        tres = float(getattr(self.f, "tres", 0.0)) if tres is None else tres
         rc = self.lib.beom_step_phase(self.h, tstp, tres, float(p.dtd8), float(p.dt_r),
                                       float(p.rsta), p.n_3d, phase, self._err, ERRLEN)
         if rc == -20:
@@ -399,8 +403,9 @@ class Engine:
             out[k] = t
         return out
 
-    def profile_steps(self, tstp_first: int, nsteps: int, tres: float = 0.0):
+    def profile_steps(self, tstp_first: int, nsteps: int, tres: Optional[float] = None):
         p = self.p
+        tres = float(getattr(self.f, "tres", 0.0)) if tres is None else tres
         ms = (C.c_double * 8)()
         nl = (C.c_int * 8)()
         self._check(self.lib.beom_profile_steps(self.h, tstp_first, nsteps, tres, float(p.dtd8),
@@ -487,8 +492,9 @@ class MultiEngine:
         self._check(self.lib.beom_multi_download_state(self.h, *args, self._err, ERRLEN))
         return out
 
-    def step(self, tstp_first: int, nsteps: int, tres: float = 0.0, sync: bool = True):
+    def step(self, tstp_first: int, nsteps: int, tres: Optional[float] = None, sync: bool = True):
         p = self.p
+        tres = float(getattr(self.f, "tres", 0.0)) if tres is None else tres      # a restarted run continues from its record's time
         self._check(self.lib.beom_multi_step(self.h, tstp_first, nsteps, tres, float(p.dtd8), float(p.dt_r),
                                              float(p.rsta), p.n_3d, self._err, ERRLEN))
         if sync:
@@ -523,7 +529,8 @@ class MultiEngine:
         v = [C.c_int() for _ in range(5)]
         self._check(self.lib.beom_multi_describe(self.h, *[C.byref(x) for x in v]))
         d = dict(zip(("bands_total", "bands_local", "transport", "ring", "rccl_version"), (x.value for x in v)))
-        d["transport"] = {XCHG_PEER: "hipMemcpyPeerAsync", XCHG_RCCL: "RCCL ncclSend/ncclRecv"}.get(d["transport"], "?")
+        d["transport"] = {XCHG_PEER: "hipMemcpyPeerAsync", XCHG_RCCL: "RCCL ncclSend/ncclRecv",
+                          XCHG_SHM: "POSIX shared memory (host-staged)"}.get(d["transport"], "?")
         return d
 
     def profile_start(self):
@@ -535,7 +542,7 @@ class MultiEngine:
         self._check(self.lib.beom_multi_profile_stop(self.h, ms, nl, self._err, ERRLEN))
         return list(ms)[:8], list(nl)[:8]
 
-    def profile_steps(self, tstp_first: int, nsteps: int, tres: float = 0.0):
+    def profile_steps(self, tstp_first: int, nsteps: int, tres: Optional[float] = None):
         self.profile_start()
         self.step(tstp_first, nsteps, tres, sync=False)
         return self.profile_stop()
@@ -578,25 +585,32 @@ def multi_window(p: Params, nb: int, band: int, yper: bool) -> dict:
 
 
 class BandEngine(MultiEngine):
-    """beom_multi_create_local: ONE band of a frame cut over `nb` processes, built from that band's window
+    """beom_multi_create_local[_ex]: ONE band of a frame cut over `nb` processes, built from that band's window
     only (bench.py under torchrun; exchange over RCCL).  `f` = the window's Fields (rows: south ghosts,
     owned rows, north ghosts — beom_amd.slab.build_window), `p_global` the global frame's parameters,
-    `orphan` = Fields of row mm+1 (band 0 of a frame periodic in y)."""
+    `orphan` = Fields of row mm+1 (band 0 of a frame periodic in y).  `shm_name` ("/...", the same on every
+    rank) selects the shared-memory transport instead of RCCL: ranks of one node that may share a device;
+    `loopback`: the band receives its own sends (one band alone with the whole exchange machinery: timing)."""
 
     def __init__(self, f: Fields, p_global: Params, nb: int, band: int, device: int = 0, variant: int = 0,
-                 rccl_id: Optional[bytes] = None, orphan: Optional[Fields] = None, upload: bool = True):
+                 rccl_id: Optional[bytes] = None, orphan: Optional[Fields] = None, upload: bool = True,
+                 shm_name: Optional[str] = None, loopback: bool = False):
         self.lib = load()
         self.f, self.p, self.pg = f, f.p, p_global
         self.orphan = orphan
         self.prm = make_params_struct(p_global, f, variant, 1, 0, 0)
         self._err = C.create_string_buffer(ERRLEN + 1)
         self.h = C.c_void_p()
-        idbuf = C.create_string_buffer(rccl_id, 128) if rccl_id is not None else None
+        if shm_name is not None:
+            idbuf, transport = C.create_string_buffer(shm_name.encode()), XCHG_SHM
+        else:
+            idbuf, transport = (C.create_string_buffer(rccl_id, 128) if rccl_id is not None else None), XCHG_RCCL
         st = self._statics(f)
         so = self._statics(orphan) if orphan is not None else None
-        rc = self.lib.beom_multi_create_local(
+        rc = self.lib.beom_multi_create_local_ex(
             C.byref(self.prm), nb, band, device, int(float(p_global.xper) > 0.5), int(float(p_global.yper) > 0.5),
-            idbuf, C.byref(st), C.byref(so) if so is not None else None, C.byref(self.h), self._err, ERRLEN)
+            transport | (XCHG_LOOPBACK if loopback else 0), idbuf, C.byref(st), C.byref(so) if so is not None else None,
+            C.byref(self.h), self._err, ERRLEN)
         self._check(rc)
         if upload:
             self.upload()

@@ -22,6 +22,10 @@
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <time.h>
+#include <unistd.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -29,6 +33,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <array>
+#include <string>
 #include <vector>
 
 #include "../../include/beom_hip.h"
@@ -105,6 +110,110 @@ constexpr int kNcclChar = 0;       // ncclInt8 / ncclChar (rccl.h): the rows tra
             return -300 - e_;                                                                \
         }                                                                                    \
     } while (0)
+
+// ---- ghost rows staged through a POSIX shared-memory segment (BEOM_XCHG_SHM) ---------------------------
+// One band per process, the processes on ONE node — several of them may share a device, which RCCL refuses
+// ("duplicate GPU"): the -m gpu tests run two and three ranks of beom_multi_create_local on the one GPU of
+// the box this way, through the same multi_one_step as the RCCL branch.  In stream order on a band's second
+// stream, where RCCL has its grouped send/recv:
+//     copy both send buffers into this band's slots of the segment -> host function: publish "exchange s is there"
+//     host function: wait for the north neighbour's s -> copy its south-going slot into recv_n; the same for the south
+// Slots are double-buffered by the parity of s; a band reaches exchange s + 2 only after it has seen its neighbours'
+// s + 1, and a neighbour publishes s + 1 only after its step has consumed this band's s — so no slot is overwritten
+// before it has been read.  A wait that lasts longer than BEOM_SHM_TIMEOUT_S (default 60) marks the handle failed
+// instead of hanging the stream.
+struct ShmCtl { volatile uint64_t ready; volatile uint64_t seq; char pad[112]; };      // one per band, 128 B apart
+struct ShmHdr { uint64_t magic; uint64_t nb; uint64_t xbytes; uint64_t slot_stride; };
+constexpr uint64_t kShmMagic = 0x42454f4d58434847ull;            // "BEOMXCHG"
+constexpr size_t kShmCtl0 = 4096;
+
+struct ShmXchg {
+    std::string name;
+    char *base = nullptr;
+    size_t size = 0, slot_stride = 0, data0 = 0;
+    int nb = 0;
+    bool registered = false;
+    uint64_t seq = 0;                       // exchanges issued by this band so far
+    volatile int failed = 0;                // a wait timed out (set from a host function)
+    double timeout_s = 60.0;
+    ShmCtl *ctl(int band) const { return (ShmCtl *)(base + kShmCtl0 + (size_t)band * sizeof(ShmCtl)); }
+    // what band `band` sends towards dir (0 = south, 1 = north) in exchange s
+    char *slot(int band, int dir, uint64_t s) const { return base + data0 + (((size_t)band * 2 + dir) * 2 + (size_t)(s & 1)) * slot_stride; }
+};
+
+static double mono_s() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+static void nap_us(long us) { timespec ts{0, us * 1000}; nanosleep(&ts, nullptr); }
+
+struct ShmOp { ShmXchg *x; int band; uint64_t seq; };
+// host functions (hipLaunchHostFunc): no HIP call inside
+static void shm_publish(void *p) {
+    ShmOp *op = (ShmOp *)p;
+    __atomic_store_n(&op->x->ctl(op->band)->seq, op->seq, __ATOMIC_RELEASE);
+    delete op;
+}
+static void shm_wait(void *p) {
+    ShmOp *op = (ShmOp *)p;
+    const double t0 = mono_s();
+    int spins = 0;
+    while (__atomic_load_n(&op->x->ctl(op->band)->seq, __ATOMIC_ACQUIRE) < op->seq) {
+        if (op->x->failed) break;
+        if (++spins > 2000) nap_us(20);
+        if ((spins & 1023) == 0 && mono_s() - t0 > op->x->timeout_s) { op->x->failed = 1; break; }
+    }
+    delete op;
+}
+
+static void shm_close(ShmXchg *x) {
+    if (!x) return;
+    if (x->base) {
+        if (x->registered) (void)hipHostUnregister(x->base);
+        munmap(x->base, x->size);
+    }
+    delete x;
+}
+
+// every band maps the segment `name` (created by whoever comes first), announces itself and waits for the others;
+// band 0 then removes the name, so nothing is left in /dev/shm once the last process has gone
+static int shm_open_all(ShmXchg **out, const char *name, int nb, int band, size_t xbytes, bool loopback, char *errm, int errm_len) {
+    if (!name || name[0] != '/' || strlen(name) > 200) { m_err(errm, errm_len, "beom_multi: the shared-memory transport needs a segment name \"/...\" common to all ranks"); return -3; }
+    ShmXchg *x = new ShmXchg();
+    x->name = name; x->nb = nb;
+    x->slot_stride = (xbytes + 4095) / 4096 * 4096;
+    x->data0 = (kShmCtl0 + (size_t)nb * sizeof(ShmCtl) + 4095) / 4096 * 4096;
+    x->size = x->data0 + (size_t)nb * 4 * x->slot_stride;
+    if (const char *t = getenv("BEOM_SHM_TIMEOUT_S")) { const double v = atof(t); if (v > 0.0) x->timeout_s = v; }
+    const int fd = shm_open(name, O_CREAT | O_RDWR, 0600);
+    if (fd < 0) { m_err(errm, errm_len, "beom_multi: shm_open(%s) failed: %s", name, strerror(errno)); delete x; return -33; }
+    if (ftruncate(fd, (off_t)x->size) != 0) { m_err(errm, errm_len, "beom_multi: ftruncate(%s, %zu) failed: %s", name, x->size, strerror(errno)); close(fd); delete x; return -33; }
+    void *m = mmap(nullptr, x->size, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) { m_err(errm, errm_len, "beom_multi: mmap(%s) failed: %s", name, strerror(errno)); delete x; return -33; }
+    x->base = (char *)m;
+    ShmHdr *h = (ShmHdr *)x->base;
+    if (band == 0 || loopback) { h->nb = (uint64_t)nb; h->xbytes = xbytes; h->slot_stride = x->slot_stride; __atomic_store_n(&h->magic, kShmMagic, __ATOMIC_RELEASE); }
+    __atomic_store_n(&x->ctl(band)->ready, (uint64_t)1, __ATOMIC_RELEASE);
+    const double t0 = mono_s();
+    for (;;) {
+        bool all = __atomic_load_n(&h->magic, __ATOMIC_ACQUIRE) == kShmMagic;
+        for (int b = 0; b < nb && all && !loopback; ++b) all = __atomic_load_n(&x->ctl(b)->ready, __ATOMIC_ACQUIRE) != 0;
+        if (all) break;
+        if (mono_s() - t0 > 2.0 * x->timeout_s) {
+            m_err(errm, errm_len, "beom_multi: band %d waited %.0f s for the other %d bands at segment %s", band, 2.0 * x->timeout_s, nb - 1, name);
+            shm_unlink(name); shm_close(x); return -34;
+        }
+        nap_us(200);
+    }
+    if (h->nb != (uint64_t)nb || h->xbytes != xbytes) {
+        m_err(errm, errm_len, "beom_multi: segment %s belongs to another frame (bands %llu, bytes %llu)", name, (unsigned long long)h->nb, (unsigned long long)h->xbytes);
+        shm_close(x); return -34;
+    }
+    if (band == 0 || loopback) shm_unlink(name);
+    // pinned: the copies to and from the segment are then asynchronous like any other (without it they still work, staged)
+    if (hipHostRegister(x->base, x->size, hipHostRegisterDefault) == hipSuccess) x->registered = true;
+    else (void)hipGetLastError();
+    *out = x;
+    return 0;
+}
 
 // ---- geometry ---------------------------------------------------------------------------------------
 struct Band {
@@ -234,6 +343,8 @@ struct beom_multi {
     std::vector<char> pending;     // an exchange into this band is in flight
     std::vector<double *> send_s, recv_s, send_n, recv_n;   // device buffers on the band's device
     std::vector<nccl_comm> comm;
+    ShmXchg *shm = nullptr;        // BEOM_XCHG_SHM: the segment shared by the bands' processes
+    bool loopback = false;         // BEOM_XCHG_LOOPBACK: this band receives what it sends (timing rehearsals)
     size_t xbytes = 0;
     long long n_split = 0, n_plain = 0;   // band-steps taken in two phases / in one piece
     // companion frame of a y-periodic ring (lives with band 0): rows 1..kMiniLo, Mr-3..Mr, Mr+1
@@ -248,8 +359,9 @@ struct beom_multi {
     int local_of(int gidx) const { for (int k = 0; k < n; ++k) if (band[k].index == gidx) return k; return -1; }
     bool has_s(int k) const { return ring || band[k].index > 0; }
     bool has_n(int k) const { return ring || band[k].index < nb - 1; }
-    int south_of(int k) const { return (band[k].index - 1 + nb) % nb; }
-    int north_of(int k) const { return (band[k].index + 1) % nb; }
+    int south_of(int k) const { return loopback ? band[k].index : (band[k].index - 1 + nb) % nb; }
+    int north_of(int k) const { return loopback ? band[k].index : (band[k].index + 1) % nb; }
+    int rank_of(int gidx) const { return loopback ? 0 : gidx; }        // RCCL rank of a band (a looped-back band is alone in its communicator)
 };
 
 namespace {
@@ -271,6 +383,7 @@ void destroy_all(beom_multi *M) {
         for (hipEvent_t e : {M->ev_lo, M->ev_hi, M->ev_free}) if (e) (void)hipEventDestroy(e);
         if (M->mini_s) (void)hipStreamDestroy(M->mini_s);
     }
+    if (M->shm) { if (M->n > 0) (void)hipSetDevice(M->dev[0]); shm_close(M->shm); M->shm = nullptr; }
     for (int k = 0; k < M->n; ++k) {
         (void)hipSetDevice(M->dev[k]);
         if (k < (int)M->comm.size() && M->comm[k] && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(M->comm[k]);
@@ -448,6 +561,11 @@ int init_transport(beom_multi *M, const void *rccl_id, char *errm, int errm_len)
         }
         return 0;
     }
+    if (M->transport == BEOM_XCHG_SHM) {
+        if (M->n != 1) { m_err(errm, errm_len, "beom_multi: the shared-memory transport carries one band per process"); return -3; }
+        M_HIP(hipSetDevice(M->dev[0]));
+        return shm_open_all(&M->shm, (const char *)rccl_id, M->nb, M->band[0].index, M->xbytes, M->loopback, errm, errm_len);
+    }
     if (M->transport != BEOM_XCHG_RCCL) { m_err(errm, errm_len, "beom_multi: unknown transport %d", M->transport); return -3; }
     if (!(all_local || M->n == 1)) { m_err(errm, errm_len, "beom_multi: RCCL transport: all bands in one process, or one band per process"); return -3; }
     if (!g_rccl.load(errm, errm_len)) return -31;
@@ -462,7 +580,7 @@ int init_transport(beom_multi *M, const void *rccl_id, char *errm, int errm_len)
         nccl_uid id;
         std::memcpy(&id, rccl_id, sizeof(id));
         M_HIP(hipSetDevice(M->dev[0]));
-        M_NCCL(g_rccl.CommInitRank(&M->comm[0], M->nb, id, M->band[0].index));
+        M_NCCL(g_rccl.CommInitRank(&M->comm[0], M->loopback ? 1 : M->nb, id, M->rank_of(M->band[0].index)));
     }
     return 0;
 }
@@ -671,8 +789,17 @@ int beom_multi_window(const beom_params *prm, int nb, int band, int yper, int *o
 int beom_multi_create_local(const beom_params *prm, int nb, int band, int device, int xper, int yper,
                             const void *rccl_id, const beom_statics *win, const beom_statics *orphan,
                             beom_multi_handle *out, char *errm, int errm_len) {
+    return beom_multi_create_local_ex(prm, nb, band, device, xper, yper, BEOM_XCHG_RCCL, rccl_id, win, orphan, out, errm, errm_len);
+}
+
+int beom_multi_create_local_ex(const beom_params *prm, int nb, int band, int device, int xper, int yper,
+                               int transport_and_flags, const void *xchg_id, const beom_statics *win, const beom_statics *orphan,
+                               beom_multi_handle *out, char *errm, int errm_len) {
     if (!prm || !out || !win || !win->fcor || !win->h_th || !win->nudg || !win->fnud) { m_err(errm, errm_len, "beom_multi_create_local: null argument"); return -1; }
     *out = nullptr;
+    const int transport = transport_and_flags & 0xff;
+    const void *rccl_id = xchg_id;
+    if (transport != BEOM_XCHG_RCCL && transport != BEOM_XCHG_SHM) { m_err(errm, errm_len, "beom_multi_create_local: one band per process exchanges over RCCL or shared memory"); return -3; }
     if (band < 0 || band >= nb) { m_err(errm, errm_len, "beom_multi_create_local: band %d of %d", band, nb); return -3; }
     M_RC(check_frame(prm, nb, yper, false, false, errm, errm_len));
     const bool ring = yper != 0;
@@ -682,7 +809,8 @@ int beom_multi_create_local(const beom_params *prm, int nb, int band, int device
     }
     beom_multi *M = new beom_multi();
     M->P = *prm; M->nb = nb; M->n = 1; M->n1g = (size_t)prm->ndeg + 1;
-    M->ring = ring; M->xper = xper != 0; M->transport = BEOM_XCHG_RCCL; M->local_mode = true;
+    M->ring = ring; M->xper = xper != 0; M->transport = transport; M->local_mode = true;
+    M->loopback = (transport_and_flags & BEOM_XCHG_LOOPBACK) != 0;
     M->dev.assign(1, device);
     size_vectors(M);
     M->band.push_back(make_band(prm, nb, band, ring));
@@ -772,6 +900,7 @@ int beom_multi_sync(beom_multi_handle M, char *errm, int errm_len) {
     }
     if (M->mini) { M_HIP(hipSetDevice(M->dev[M->mini_k])); M_HIP(hipStreamSynchronize(M->mini_s)); }
     M_HIP(hipGetLastError());
+    if (M->shm && M->shm->failed) { M->failed = true; m_err(errm, errm_len, "beom_multi: a neighbour's ghost rows did not arrive within %.0f s (shared-memory transport)", M->shm->timeout_s); return -35; }
     return 0;
 }
 
@@ -1047,7 +1176,7 @@ int beom_multi_profile_stop(beom_multi_handle M, double *ms, int *launches, char
     for (int k = 0; k < M->n; ++k) {
         double m[8] = {0}; int l[8] = {0};
         M_RC(beom_profile_stop(M->eng[k], m, l, errm, errm_len));
-        for (int c = 0; c < 7; ++c) if (m[c] > ms[c]) { ms[c] = m[c]; launches[c] = l[c]; }
+        for (int c = 0; c < 8; ++c) if (m[c] > ms[c]) { ms[c] = m[c]; launches[c] = l[c]; }
     }
     return 0;
 }
@@ -1060,6 +1189,7 @@ static int multi_one_step(beom_multi *M, int t, double tres, double dtd8, double
     const int n = M->n;
     const int mk = M->mini_k;
     std::vector<char> split(n, 0);
+    if (M->shm && M->shm->failed) { m_err(errm, errm_len, "beom_multi: a neighbour's ghost rows did not arrive within %.0f s (shared-memory transport)", M->shm->timeout_s); return -35; }
     // the companion frame's copy of rows 1..6 (state before this step); later steps pack it right after the step
     if (M->mini && !M->lo_packed) {
         M_HIP(hipSetDevice(M->dev[mk]));
@@ -1145,15 +1275,37 @@ static int multi_one_step(beom_multi *M, int t, double tres, double dtd8, double
         // sends in the order (south, north), receives in the order (north, south): with two bands in a ring, or
         // one, both neighbours are the same peer and RCCL matches a pair's messages in issue order
         M_NCCL(g_rccl.GroupStart());
-        for (int k = 0; k < n; ++k) {
-            M_HIP(hipSetDevice(M->dev[k]));
-            const int S = M->south_of(k), N = M->north_of(k);
-            if (M->has_s(k)) M_NCCL(g_rccl.Send(M->send_s[k], M->xbytes, kNcclChar, S, M->comm[k], M->comm_s[k]));
-            if (M->has_n(k)) M_NCCL(g_rccl.Send(M->send_n[k], M->xbytes, kNcclChar, N, M->comm[k], M->comm_s[k]));
-            if (M->has_n(k)) M_NCCL(g_rccl.Recv(M->recv_n[k], M->xbytes, kNcclChar, N, M->comm[k], M->comm_s[k]));
-            if (M->has_s(k)) M_NCCL(g_rccl.Recv(M->recv_s[k], M->xbytes, kNcclChar, S, M->comm[k], M->comm_s[k]));
+        int e = 0;                                  // (a failed call must not leave the process-wide group open)
+        for (int k = 0; k < n && !e; ++k) {
+            if (hipSetDevice(M->dev[k]) != hipSuccess) { e = 1; break; }
+            const int S = M->rank_of(M->south_of(k)), N = M->rank_of(M->north_of(k));
+            if (!e && M->has_s(k)) e = g_rccl.Send(M->send_s[k], M->xbytes, kNcclChar, S, M->comm[k], M->comm_s[k]);
+            if (!e && M->has_n(k)) e = g_rccl.Send(M->send_n[k], M->xbytes, kNcclChar, N, M->comm[k], M->comm_s[k]);
+            if (!e && M->has_n(k)) e = g_rccl.Recv(M->recv_n[k], M->xbytes, kNcclChar, N, M->comm[k], M->comm_s[k]);
+            if (!e && M->has_s(k)) e = g_rccl.Recv(M->recv_s[k], M->xbytes, kNcclChar, S, M->comm[k], M->comm_s[k]);
         }
-        M_NCCL(g_rccl.GroupEnd());
+        const int ge = g_rccl.GroupEnd();
+        if (e || ge) { m_err(errm, errm_len, "RCCL ghost exchange failed: %s", g_rccl.GetErrorString(e ? e : ge)); return -300 - (e ? e : ge); }
+    } else if (M->transport == BEOM_XCHG_SHM) {
+        // the same place in the same stream order as the grouped send/recv above (see ShmXchg)
+        ShmXchg *x = M->shm;
+        const int k = 0;
+        const uint64_t sq = ++x->seq;
+        const int me = M->band[k].index;
+        M_HIP(hipSetDevice(M->dev[k]));
+        if (M->has_s(k)) M_HIP(hipMemcpyAsync(x->slot(me, 0, sq), M->send_s[k], M->xbytes, hipMemcpyDeviceToHost, M->comm_s[k]));
+        if (M->has_n(k)) M_HIP(hipMemcpyAsync(x->slot(me, 1, sq), M->send_n[k], M->xbytes, hipMemcpyDeviceToHost, M->comm_s[k]));
+        M_HIP(hipLaunchHostFunc(M->comm_s[k], shm_publish, new ShmOp{x, me, sq}));
+        if (M->has_n(k)) {          // what my north neighbour sent south (looped back: what I sent myself)
+            const int q = M->north_of(k), dir = M->loopback ? (M->has_s(k) ? 0 : 1) : 0;
+            M_HIP(hipLaunchHostFunc(M->comm_s[k], shm_wait, new ShmOp{x, q, sq}));
+            M_HIP(hipMemcpyAsync(M->recv_n[k], x->slot(q, dir, sq), M->xbytes, hipMemcpyHostToDevice, M->comm_s[k]));
+        }
+        if (M->has_s(k)) {
+            const int q = M->south_of(k), dir = M->loopback ? (M->has_n(k) ? 1 : 0) : 1;
+            M_HIP(hipLaunchHostFunc(M->comm_s[k], shm_wait, new ShmOp{x, q, sq}));
+            M_HIP(hipMemcpyAsync(M->recv_s[k], x->slot(q, dir, sq), M->xbytes, hipMemcpyHostToDevice, M->comm_s[k]));
+        }
     }
     for (int k = 0; k < n; ++k) {
         const Band &s = M->band[k];

@@ -60,6 +60,7 @@ class Fields:
     Ow: Optional[np.ndarray] = None
     Os: Optional[np.ndarray] = None
     Osum_: Optional[np.ndarray] = None
+    tres: float = 0.0     # time of the record a restarted run (rsta = 1) continues from, days (:1311-1325); ctim = tres + dtd8*tstp
 
     @property
     def ndeg(self): return self.p.ndeg
@@ -396,10 +397,44 @@ def fcor_mean_r4(ior4: np.ndarray) -> np.float32:
     return np.float32(np.add.reduce(ior4.ravel(order="F"), dtype=np.float32) / np.float32(ior4.size))
 
 
+def apply_restart_record(f: Fields, eta: np.ndarray, u4: np.ndarray, v4: np.ndarray, tres: float) -> Fields:
+    """read_restart_record / read_array (private_mod.f95:1299-1420): the state a run with rsta = 1 starts from is
+    the LAST complete output record of the previous run — real*4 `u___`, `v___` widened, and the interface
+    elevations `eta_` turned back into thicknesses with the real*4 h_0 of h_0.bin (which init has just rewritten,
+    :185-193): hlay = (h_0 + eta_k) - eta_k+1, times mk_n.  eta, u4, v4: [nlay, ndeg] real*4; tres = the last
+    entry of time.txt (days)."""
+    nlay = f.p.nlay
+    eta = np.asarray(eta, dtype=f4).reshape(nlay, f.p.ndeg)
+    h0 = f.h_0[:, 1:].astype(f4)
+    for il in range(nlay):
+        h = h0[il].astype(f8) + eta[il].astype(f8)
+        if il < nlay - 1:
+            h = h - eta[il + 1].astype(f8)
+        f.hlay[il, 1:] = h * f.mk_n[1:]
+    f.u[:, 1:] = np.asarray(u4, dtype=f4).reshape(nlay, f.p.ndeg).astype(f8)
+    f.v[:, 1:] = np.asarray(v4, dtype=f4).reshape(nlay, f.p.ndeg).astype(f8)
+    f.tres = float(tres)
+    return f
+
+
+def restart_from_files(f: Fields, odir_files: Dict[str, bytes]) -> Fields:
+    """The same from the previous run's output files: {"time.txt": text, "eta_.bin" | "u___.bin" | "v___.bin": bytes}."""
+    stamps = []
+    for line in str(odir_files["time.txt"]).split("\n"):       # list-directed reads until the first failure (:1313-1322)
+        try:
+            stamps.append(float(line.split()[0].replace("D", "E").replace("d", "e")))
+        except (ValueError, IndexError):
+            break
+    irec, n = len(stamps), f.p.nlay * f.p.ndeg
+    rec = lambda k: np.frombuffer(bytes(odir_files[k]), dtype="<f4")[(irec - 1) * n: irec * n]
+    return apply_restart_record(f, rec("eta_.bin"), rec("u___.bin"), rec("v___.bin"), stamps[-1])
+
+
 def read_input_data(p: Params, idir: Optional[str] = None,
                     files: Optional[Dict[str, np.ndarray]] = None, window: Optional[dict] = None) -> Fields:
     """private_mod.f95:105-250 (without the output calls).  Inputs come from
     ``idir/*.bin`` or from an in-memory dict of arrays (rounded to real*4 here).
+    A restarted run (rsta = 1) then takes its state from the previous run's last record: restart_from_files.
 
     window (multi-GPU, beom_amd/slab.py): the frame described by `p` and `files` is the band of rows
     j0..j1 of a taller DENSE frame — frame row 0 is the taller frame's row j0-1 (looked at by the wet

@@ -262,6 +262,13 @@ int beom_profile_steps(beom_handle h, int tstp_first, int nsteps,
 #define BEOM_XCHG_PEER 0     /* hipMemcpyPeerAsync between the bands of ONE process (xGMI peer copies)      */
 #define BEOM_XCHG_RCCL 1     /* grouped ncclSend/ncclRecv (librccl.so.1, bound at run time): all bands in one
                                 process (ncclCommInitAll, distinct devices) or one band per process          */
+#define BEOM_XCHG_SHM  2     /* one band per process, the processes on ONE node: the packed ghost rows are staged through a
+                                POSIX shared-memory segment, in the same stream order as the RCCL send/recv (device -> segment,
+                                publish; wait for the neighbour, segment -> device).  Unlike RCCL it lets several ranks share
+                                a device: the -m gpu tests run 2 and 3 ranks of beom_multi_create_local on one GPU this way  */
+#define BEOM_XCHG_LOOPBACK 0x200 /* flag for beom_multi_create_local_ex: the band receives what it sends itself (its own edge
+                                rows arrive as its ghost rows).  ONE band of a frame cut nb ways then runs alone with the
+                                whole exchange machinery — a timing rehearsal; the values are not the frame's              */
 #define BEOM_XCHG_RING1 0x100 /* flag for beom_multi_create_ex: cut a frame periodic in y as a ring even when
                                 there is ONE band (it then exchanges with itself; exercises the ring form)   */
 
@@ -356,6 +363,13 @@ int beom_multi_window(const beom_params *prm, int nb, int band, int yper,
 int beom_multi_create_local(const beom_params *prm, int nb, int band, int device, int xper, int yper,
                             const void *rccl_id, const beom_statics *window, const beom_statics *orphan,
                             beom_multi_handle *out, char *errm, int errm_len);
+/* The same with the transport named: BEOM_XCHG_RCCL (xchg_id = the 128-byte unique id, as above) or BEOM_XCHG_SHM
+ * (xchg_id = NUL-terminated name "/..." of a shared-memory segment, the same on all nb ranks and not in use by any other
+ * job; created by whoever comes first, removed again once all nb ranks have attached), optionally | BEOM_XCHG_LOOPBACK. */
+int beom_multi_create_local_ex(const beom_params *prm, int nb, int band, int device, int xper, int yper,
+                               int transport_and_flags, const void *xchg_id,
+                               const beom_statics *window, const beom_statics *orphan,
+                               beom_multi_handle *out, char *errm, int errm_len);
 int beom_multi_upload_local(beom_multi_handle h, const beom_state *window, const beom_state *orphan,
                             char *errm, int errm_len);
 int beom_multi_download_local(beom_multi_handle h, beom_state *window, beom_state *orphan,

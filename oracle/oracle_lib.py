@@ -86,6 +86,7 @@ class Oracle:
     def __init__(self, f, variant: int = 0, per_layer_scratch: bool = True):
         self.lib = load()
         self.p = f.p
+        self.f = f
         self.prm = make_params_struct(f.p, f, variant)
         n1 = f.p.ndeg + 1
         self.a = {}
@@ -118,8 +119,9 @@ class Oracle:
         self.st.segm = self.segm.ctypes.data if self.segm is not None else None
         self.st.nseg = self.segm.shape[1] if self.segm is not None else 0
 
-    def step(self, tstp_first: int, nsteps: int, tres: float = 0.0):
+    def step(self, tstp_first: int, nsteps: int, tres=None):
         p = self.p
+        tres = float(getattr(self.f, "tres", 0.0)) if tres is None else tres      # restarted runs (rsta = 1, :1311-1325)
         rc = self.lib.oracle_step(C.byref(self.prm), C.byref(self.st), tstp_first, nsteps, tres,
                                   float(p.dtd8), float(p.dt_r), float(p.rsta), p.n_3d)
         if rc != 0:

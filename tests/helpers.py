@@ -10,13 +10,17 @@ import copy
 
 import numpy as np
 
-from beom_amd.grid import read_input_data
+from beom_amd.grid import read_input_data, restart_from_files
 from beom_amd.params import Params
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 GOLDEN_STEPS = (1, 2, 3, 4, 5, 10)
 STATE = ("hlay", "u", "v", "h_u", "h_v", "rs_h", "dmdx", "dmdy", "v_cc", "v_ll", "tt3d", "tb3d", "tu3d")
 SCRATCH = ("mont", "rvor", "pvor", "dive", "d2hx", "d2hy")
+
+
+def _fname(key):
+    return key.replace("_bin", ".bin").replace("_txt", ".txt")
 
 
 def golden_names():
@@ -33,12 +37,18 @@ class Golden:
         self.p = Params.from_json(json.loads(str(self.z["params_json"])))
         self.variant = 1 if str(self.z["engine"]) == "private_mod3d.f95" else 0
         self.files = {k[3:]: self.z[k] for k in self.z.files if k.startswith("in_")}
+        # restart fixtures (rsta = 1): the output files of the run that is continued, as the reference found them in odir
+        self.pre = {_fname(k[9:]): (str(self.z[k]) if k.endswith("_txt") else self.z[k].tobytes())
+                    for k in self.z.files if k.startswith("pre_file_")}
 
     def fields(self):
         """The init mirror's module state for this fixture.  Built once per session and name (the outcropping rest state is an
         iteration in numpy: seconds); callers get their own shallow copy — they set attributes (invf, p), never array elements."""
         if self.name not in _FIELDS:
-            _FIELDS[self.name] = read_input_data(self.p, files=self.files)
+            f = read_input_data(self.p, files=self.files)
+            if float(self.p.rsta) > 0.5:
+                restart_from_files(f, self.pre)
+            _FIELDS[self.name] = f
         return copy.copy(_FIELDS[self.name])
 
     def static(self, key):
