@@ -142,8 +142,6 @@ def load(path: Optional[str] = None) -> C.CDLL:
     lib.beom_sync.argtypes = [H, cp, ci]
     lib.beom_set_stream.argtypes = [H, C.c_void_p, ci]
     lib.beom_set_option.argtypes = [H, cp, ci]
-    lib.beom_graph_stats.argtypes = [H, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
-    lib.beom_graph_stats.restype = ci
     lib.beom_set_open_boundaries.argtypes = [H, ci, ipp, cp, ci]
     lib.beom_multi_set_open_boundaries.argtypes = [H, ci, ipp, cp, ci]
     lib.beom_download_outputs.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, dpp, C.POINTER(ci), cp, ci]
@@ -213,7 +211,7 @@ def load(path: Optional[str] = None) -> C.CDLL:
     return lib
 
 
-EXPORTS = ("beom_abi_version", "beom_device_count", "beom_device_pci_bus_id", "beom_graph_stats", "beom_download_diag", "beom_create", "beom_destroy", "beom_set_rigid_lid", "beom_download_pressure",
+EXPORTS = ("beom_abi_version", "beom_device_count", "beom_device_pci_bus_id", "beom_download_diag", "beom_create", "beom_destroy", "beom_set_rigid_lid", "beom_download_pressure",
            "beom_upload_state", "beom_download_state", "beom_download_scratch", "beom_step",
            "beom_sync", "beom_update_h", "beom_update_mont_rvor_pvor_dive_kine",
            "beom_update_viscosity", "beom_update_u", "beom_update_v", "beom_rebuild_fluxes",
@@ -375,11 +373,6 @@ class Engine:
         nl = (C.c_int * 8)()
         self._check(self.lib.beom_profile_stop(self.h, ms, nl, self._err, ERRLEN))
         return list(ms)[:8], list(nl)[:8]
-
-    def graph_stats(self) -> dict:
-        a, b = C.c_longlong(), C.c_longlong()
-        self.lib.beom_graph_stats(self.h, C.byref(a), C.byref(b))
-        return {"graph_steps": a.value, "eager_steps": b.value}
 
     def field_tensors(self, names=("hlay", "u", "v", "h_u", "h_v")):
         """Zero-copy torch views [nlay, layer stride] of the device-resident prognostic fields.  Handles on the

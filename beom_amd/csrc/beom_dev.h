@@ -58,7 +58,6 @@ struct DevView {
     int zero_visc;                // v_cc = v_ll = +0 everywhere and never refreshed: the viscous products are +-0
     int lean_d2h;                 // fused sweep stores d2hx, d2hy only where the fused u+v sweep reads them
     int edge_global;              // k_uv_fused: edge workgroups read global memory throughout (A/B switch; default: staged by lookup)
-    int only_shallow;             // k_mont_visc: only the tiles a frame-edge workgroup of k_muv reads (k_muv derives the rest itself)
     // biharmonic viscosity (svis > 0, :2508-2599): Laplacians and thickness-weighted fluxes
     double *delu, *delv, *uu4, *vv4; double svis;
     // packed layout: per run of 64 cells (dN, dS) if the run is a uniform wet interior, else (0, 0); may be null
@@ -80,6 +79,12 @@ struct DevView {
     double i_dl, i_gr, i_ns, i_r0, i_r1, i_rn[BEOM_MAX_LAYERS];
     // which optional terms are live (wave-uniform branches)
     int has_hdot, has_tide, has_bodf, has_nudg, has_stress, has_wind, has_hto;
+    // distribute_stress inside the fused momentum sweep (uv_core; set per launch by the engine: ocrp = 0, a stress refresh on
+    // every step, steps > 3): the wind stress at real cells only (0 in the sentinel and in every slot that is no cell, as
+    // tt3d is), bottom / top drag switched on, the densities of the top and the bottom layer
+    int stress_fold, has_bot, has_top;
+    const double *taus_cells;
+    double rho_top, rho_bot;
 };
 
 // ---- tiles of the selected strips --------------------------------------------------------

@@ -74,6 +74,10 @@ struct beom_engine {
     // geometry of the launches
     dim3 grid_cells0, grid_cells_layers_flat;
     bool wind = false, bot = false, top = false;
+    // distribute_stress inside the fused momentum sweep (option "fold_stress", default on): possible when the fractions are
+    // constants (ocrp = 0) and nothing the sweep would have to read was uploaded into an array the engine does not refresh
+    bool fold_stress = true, fold_static_ok = false;
+    bool up_tt = false, up_tb = false, up_tu = false;   // a non-zero tt3d / tb3d / tu3d has been uploaded
     float *h0r4_dev = nullptr, *out4[3] = {nullptr, nullptr, nullptr};   // device-side output staging
     float *diag4[3] = {nullptr, nullptr, nullptr};
     double *scan_dev = nullptr;
@@ -86,28 +90,14 @@ struct beom_engine {
     bool lean_visc = true;             // zero viscosity (dvis = bvis = 0, v_cc = v_ll = +0): fused pair drops the viscous products
     bool visc_all_zero = true;         // no non-(+0) v_cc / v_ll has been uploaded
     bool lean_d2h = true;              // fused pair: d2hx, d2hy re-derived from hlay in k_uv_fused, not stored by k_mont_visc
-    bool fuse_muv = false;             // Montgomery + Leith folded into the momentum sweep (k_muv): measured SLOWER than the two
-                                       // fused sweeps (4.4 vs 3.1 ms at 4096^2 x 4: 229 VGPRs, two waves per SIMD), so opt-in
-    // Launch-bound frames (a few hundred thousand cells: a sweep takes a few microseconds): runs of time steps are
-    // replayed from HIP graphs.  A graph holds one full PERIOD of the pointer rotations (histories, ping-pong
-    // partners, u/v order), so replaying it leaves every pointer where the capture found it.
-    struct StepGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int period = 0, parity = 0; std::vector<void *> key; };
-    std::vector<StepGraph> graphs;
-    int use_graph = 0;                 // option "graph": 0 = never (default: measured no gain), 1 = whenever the step allows,
-                                       // -1 = automatic (dense frames of at most 4 M cell-layers)
-    long long graph_steps = 0, eager_steps = 0;
     // rigid lid (rgld = 1): the caller's subc and the packed -> device index map, kept for beom_set_rigid_lid
     std::vector<int32_t> subc_host, neig_host, dev_index;
     bool lid = false, lid_ready = false;
     int profile_stride = 1;            // option "profile_stride"
-    hipEvent_t ev_h1 = nullptr, ev_mv1 = nullptr;   // split steps: phase 1 has run update_h / the Montgomery sweep (phase 2 may be on another stream)
+    bool split_prod = false;           // split steps: part 1's Montgomery sweep left the viscous products for parts 2 and 3
     bool tile4 = false;                // the tiled sweeps run the 64 x 4 geometry (frames of one or two rounds of workgroups)
     char last_err[512] = {0};
 };
-static void graphs_clear(beom_engine *E) {
-    for (auto &g : E->graphs) { if (g.exec) (void)hipGraphExecDestroy(g.exec); if (g.graph) (void)hipGraphDestroy(g.graph); }
-    E->graphs.clear();
-}
 
 namespace {
 
@@ -374,6 +364,12 @@ int beom_create(const beom_params *prm, int device, const int32_t *neig, const i
     UP(fcor, fcor, 1, 1) UP(h_th, h_th, 1, 1) UP(h_to, h_to, 1, 1)
     UP(nudg, nudg, 3, 1) UP(fnud, fnud, 3 * nl, 1) UP(hdot, hdot, nl, 1)
     UP(tide, tide, 3, 2) UP(taus, taus, 2, 1)
+    {   // the wind stress as tt3d holds it: at real cells only (distribute_stress writes cells 1..ndeg, :1945-1966; index 0 and
+        // every device slot that is no cell stay +0)
+        std::vector<double> tc(2 * n1h, 0.0);
+        if (taus) { std::memcpy(tc.data(), taus, 2 * n1h * sizeof(double)); tc[0] = 0.0; tc[n1h] = 0.0; }
+        UP(taus_cells, tc.data(), 2, 1)
+    }
 #undef UP
     {   // bodf(nlay, 2): no cell dimension
         double *q = nullptr;
@@ -420,20 +416,26 @@ int beom_create(const beom_params *prm, int device, const int32_t *neig, const i
     d.keep_diag = 0; d.lean_d2h = 0; E->lean_d2h = true;
     E->fuse = getenv("BEOM_NO_FUSE") == nullptr;
     E->fuse_uv = getenv("BEOM_NO_FUSE") == nullptr && getenv("BEOM_NO_FUSE_UV") == nullptr;
-    E->fuse_muv = getenv("BEOM_MUV") != nullptr;
     // frames of few rounds of workgroups: the 64 x 4 tile geometry, one row per thread (a workgroup's lifetime is what the
     // step time is made of there).  Same box, us per step, 64 x 8 -> 64 x 4: stommel 128^2 31.2 -> 24.0, soliton 2048x256
     // 53.5 -> 43.6, 1024x128x4 74.8 -> 56.3, sill 4096x512x4 614 -> 596; jet 2048^2 x 2 535 -> 557, 4096^2 x 4 and larger: slower
     E->tile4 = E->dense && (long long)((d.L + 63) / 64) * ((d.M + 7) / 8) <= 5000;
     if (getenv("BEOM_TILE4")) E->tile4 = E->dense && atoi(getenv("BEOM_TILE4")) != 0;      // (A/B switch)
-    if (E->lid) E->fuse = E->fuse_uv = E->fuse_muv = false;      // the lid's flux rebuild reads the stored d2hx, d2hy of the last layer
+    if (E->lid) E->fuse = E->fuse_uv = false;      // the lid's flux rebuild reads the stored d2hx, d2hy of the last layer
     d.edge_global = getenv("BEOM_EDGE_GLOBAL") != nullptr;
     E->wind = false;
     if (taus) for (size_t i = 0; i < 2 * n1h; ++i) if (std::fabs(taus[i]) > 1.e-7) { E->wind = true; break; }   // :1945
     E->bot = prm->bdrg > 1.e-7;                                                                                  // :1969
     E->top = prm->tdrg > 1.e-7;                                                                                  // :1991
-    d.has_wind = E->wind;
+    d.has_wind = E->wind; d.has_bot = E->bot; d.has_top = E->top;
     d.has_stress = E->wind || E->bot || E->top;
+    d.stress_fold = 0;
+    d.rho_top = prm->rhon[0]; d.rho_bot = prm->rhon[nl - 1];
+    {
+        bool neg0 = false;                         // a body force of exactly -0 would make the sign of a skipped +-0 visible
+        if (bodf) for (size_t i = 0; i < 2 * nl; ++i) if (bodf[i] == 0.0 && std::signbit(bodf[i])) neg0 = true;
+        E->fold_static_ok = E->dense && prm->ocrp < 0.5 && !E->lid && d.has_stress && !neg0 && getenv("BEOM_NO_FOLD_STRESS") == nullptr;
+    }
 #define AL(name, n) if ((rc = dev_alloc(E, &d.name, (size_t)(n), errm, errm_len))) { beom_destroy(E); return rc; }
     AL(hlay, nl * n1) AL(u, nl * n1) AL(v, nl * n1) AL(h_u, nl * n1) AL(h_v, nl * n1)
     AL(rs[0], nl * n1) AL(rs[1], nl * n1)
@@ -471,10 +473,8 @@ int beom_destroy(beom_handle E) {
     if (!E) return 0;
     (void)hipSetDevice(E->device);
     if (E->stream) (void)hipStreamSynchronize(E->stream);
-    graphs_clear(E);
     for (void *p : E->allocs) (void)hipFree(p);
     if (E->stage) (void)hipFree(E->stage);
-    for (hipEvent_t ev : {E->ev_h1, E->ev_mv1}) if (ev) (void)hipEventDestroy(ev);
     if (E->timer) { for (hipEvent_t ev : E->timer->ev) (void)hipEventDestroy(ev); delete E->timer; }
     if (E->own_stream) (void)hipStreamDestroy(E->own_stream);
     delete E;
@@ -532,7 +532,6 @@ int beom_upload_state(beom_handle E, const double *hlay, const double *u, const 
                       const double *tb3d, const double *tu3d, char *errm, int errm_len) {
     if (!E) { set_err(errm, errm_len, "null handle"); return -1; }
     HIP_TRY(hipSetDevice(E->device));
-    graphs_clear(E);                   // (the zero-viscosity and stress switches below select launches)
     DevView &d = E->d;
     const size_t nl = (size_t)d.nlay, n = ((size_t)d.ndeg + 1) * nl;
     int rc;
@@ -550,7 +549,10 @@ int beom_upload_state(beom_handle E, const double *hlay, const double *u, const 
     if ((rc = hist_in(E, d.dmx, 3, dmdx, errm, errm_len))) return rc;
     if ((rc = hist_in(E, d.dmy, 3, dmdy, errm, errm_len))) return rc;
     // a caller may upload stresses computed elsewhere: keep those terms live
-    if (any_nonzero(tt3d, 2 * n) || any_nonzero(tb3d, 2 * n) || any_nonzero(tu3d, 2 * n)) d.has_stress = 1;
+    if (any_nonzero(tt3d, 2 * n)) E->up_tt = true;
+    if (any_nonzero(tb3d, 2 * n)) E->up_tb = true;
+    if (any_nonzero(tu3d, 2 * n)) E->up_tu = true;
+    if (E->up_tt || E->up_tb || E->up_tu) d.has_stress = 1;
     // zero-viscosity shortcut: only while v_cc, v_ll are +0 bit for bit (-0 would flip the sign of the products)
     for (const double *a : {v_cc, v_ll})
         if (a) for (size_t i = 0; i < n && E->visc_all_zero; ++i) { uint64_t b; memcpy(&b, &a[i], 8); if (b != 0) E->visc_all_zero = false; }
@@ -800,21 +802,6 @@ static void launch_uv_fused(beom_engine *E, bool first_x, bool prod, double gene
     else raw_uv_fused_t8(E, first_x, prod, zv, gene, ramp, ctim);
     if (swap) uv_fused_swap(E, first_x);
 }
-// Montgomery + Leith + u + v as ONE sweep (k_muv) after the edge tiles' k_mont_visc; false if no instantiation
-// (two calls so that a split step can give each its own rows, as for the separate sweeps)
-static bool launch_muv_edges(beom_engine *E, bool leith) {
-    E->d.only_shallow = 1;
-    const bool ok = launch_mont_visc(E, true, leith, false);
-    E->d.only_shallow = 0;
-    return ok;
-}
-static bool launch_muv(beom_engine *E, bool first_x, bool leith, double gene, double ramp, double ctim, bool swap = true) {
-    const bool zv = E->d.zero_visc;
-    if (E->tile4) raw_muv_t4(E, first_x, leith, zv, gene, ramp, ctim);
-    else raw_muv_t8(E, first_x, leith, zv, gene, ramp, ctim);
-    if (swap) uv_fused_swap(E, first_x);
-    return true;
-}
 static bool can_fuse(const beom_engine *E, int n_3d, bool first3) {
     // either every step refreshes the viscosity (dvis > 1e-3 and n_3d = 1, :2268) — Montgomery + Leith
     // in one sweep — or no step after the third ever does (dvis <= 1e-3, svis = 0): v_cc, v_ll stand
@@ -864,7 +851,7 @@ int beom_distribute_stress(beom_handle E) { NEED(E); launch_stress(E); return LA
 }  // extern "C"
 
 // Per-step scalars of integrate_time (private_mod.f95:1858-1901).
-struct StepScalars { double ctim, ramp, gene; bool first3, upst, stress, fused, fused_uv, muv; int n_3d; };
+struct StepScalars { double ctim, ramp, gene; bool first3, upst, stress, fused, fused_uv; int n_3d; };
 static StepScalars step_scalars(const beom_engine *E, int tstp, double tres, double dtd8, double dt_r,
                                 double rsta, int n_3d) {
     StepScalars s;
@@ -885,17 +872,23 @@ static StepScalars step_scalars(const beom_engine *E, int tstp, double tres, dou
     s.n_3d = n_3d;
     s.fused = can_fuse(E, n_3d, s.first3);
     s.fused_uv = E->dense && E->fuse_uv && !(E->P.svis > 0.0);
-    // one sweep for Montgomery, Leith, u and v: needs both fusions, the re-derived curvatures, and a viscosity that is
-    // either refreshed on every step or never again (no v_cc, v_ll to keep standing between refreshes)
-    s.muv = s.fused && s.fused_uv && E->fuse_muv && E->lean_d2h && !E->d.keep_diag && E->d.nlay <= 8 &&
-            (n_3d == 1 || !(E->P.dvis > 1.e-3)) && !E->obc;
     return s;
+}
+
+// distribute_stress of this step inside its fused momentum sweep (uv_core): the fractions are constants (ocrp = 0), every
+// step refreshes the stress (so tt3d, tb3d, tu3d are never read back; steps 2 and 3 reuse step 1's, :1863), and an array
+// the engine does not refresh holds nothing but zeros.  The three arrays then keep their values of step 3 ("keep_diag" = 1
+// keeps them current).
+static bool stress_folds(const beom_engine *E, const StepScalars &s) {
+    return E->fold_stress && E->fold_static_ok && s.fused_uv && s.stress && !s.first3 && s.n_3d == 1 && !E->d.keep_diag &&
+           (E->wind || !E->up_tt) && (E->bot || !E->up_tb) && (E->top || !E->up_tu);
 }
 
 static void one_step(beom_engine *E, int tstp, const StepScalars &s) {
     StepTimer *T = (E->timer && tstp % E->timer->stride == 0) ? E->timer : nullptr;
     if (T) T->st = E->stream;
-    if (s.stress) launch_stress(E);
+    E->d.stress_fold = stress_folds(E, s) ? 1 : 0;
+    if (s.stress && !E->d.stress_fold) launch_stress(E);
     if (E->lid) launch_lid_fluxes(E, s.first3);
     else if (s.first3) launch_rebuild(E);                          // :2166-2177
     if (T) T->begin(0);
@@ -903,14 +896,6 @@ static void one_step(beom_engine *E, int tstp, const StepScalars &s) {
     if (E->lid) launch_lid_h_epilogue(E);                          // :1648-1700
     const bool leith = E->P.dvis > 1.e-3 && s.upst;
     const bool u_first = tstp % 2 == 0;                            // :2193-2199,2276-2282
-    if (s.muv) {                                                   // :2187-2199, 2266-2282 in one sweep
-        if (T) { T->end(); T->begin(5); }
-        launch_muv_edges(E, leith);
-        if (T) { T->end(); T->begin(7); }
-        launch_muv(E, u_first, leith, s.gene, s.ramp, s.ctim);
-        if (T) T->end();
-        return;
-    }
     if (T) { T->end(); T->begin(s.fused ? 5 : 1); }
     const bool prod = s.fused && launch_mont_visc(E, s.fused_uv, leith, leith && s.n_3d > 1);              // :2187-2188, 2266-2269 in one sweep
     if (!prod) launch_mont(E, 0);
@@ -943,51 +928,7 @@ static void one_step(beom_engine *E, int tstp, const StepScalars &s) {
         hipLaunchKernelGGL(k_no_gradient_obc, g, dim3(BEOM_BLOCK), 0, E->stream, E->d, 1);
     }
     if (E->lid) { launch_lid_fluxes(E, s.first3); launch_lid_pressure(E); }       // :2206-2222, 2290-2316
-}
-
-// ---- HIP graphs for launch-bound frames -------------------------------------------------------------
-static std::vector<void *> pointer_key(const beom_engine *E) {
-    const DevView &d = E->d;
-    return {d.hlay, d.u, d.v, d.h_u, d.h_v, d.u_alt, d.v_alt, d.hu_alt, d.hv_alt, d.rs[0], d.rs[1],
-            d.dmx[0], d.dmx[1], d.dmx[2], d.dmx[3], d.dmy[0], d.dmy[1], d.dmy[2], d.dmy[3]};
-}
-// a step whose launches do not depend on tstp except through its parity: steady forward-backward stepping
-static bool graph_step_ok(const beom_engine *E, int tstp, double tres, double dtd8, double dt_r, double rsta, int n_3d) {
-    if (E->use_graph == 0 || E->timer || tstp <= 3 || n_3d != 1 || E->d.has_tide || E->d.slab || E->lid) return false;
-    if (E->use_graph < 0 && (E->d.ncell * E->d.nlay > 4000000ll || !E->dense)) return false;
-    const double ctim = tres + dtd8 * (double)tstp;
-    if (rsta < 0.5 && ctim < dt_r && E->d.has_stress) return false;      // the wind is still ramping up (:1898-1901)
-    return true;
-}
-// the graph that starts from the present pointer state at a step of this parity; captured on first use
-static beom_engine::StepGraph *graph_for(beom_engine *E, int tstp, double tres, double dtd8, double dt_r, double rsta, int n_3d) {
-    const std::vector<void *> key = pointer_key(E);
-    for (auto &g : E->graphs) if (g.parity == (tstp & 1) && g.key == key) return &g;
-    if (E->graphs.size() >= 8) graphs_clear(E);
-    beom_engine::StepGraph g;
-    g.parity = tstp & 1; g.key = key;
-    const DevView saved = E->d;          // the captured launches do not run: on any failure the rotations are taken back
-    if (hipStreamBeginCapture(E->stream, hipStreamCaptureModeRelaxed) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    int n = 0;
-    do {            // the launches of one period; the host-side rotations run as usual and come back to `key`
-        one_step(E, tstp + n, step_scalars(E, tstp + n, tres, dtd8, dt_r, rsta, n_3d));
-        ++n;
-    } while (n < 96 && !(n % 2 == 0 && pointer_key(E) == key));
-    const bool closed = pointer_key(E) == key && n % 2 == 0;
-    hipError_t e = hipStreamEndCapture(E->stream, &g.graph);
-    if (e != hipSuccess || !closed) {
-        (void)hipGetLastError();
-        if (g.graph) (void)hipGraphDestroy(g.graph);
-        E->d = saved;
-        E->use_graph = 0;                        // no period within reach / capture refused: stay eager from now on
-        return nullptr;
-    }
-    if (hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0) != hipSuccess) {
-        (void)hipGetLastError(); (void)hipGraphDestroy(g.graph); E->d = saved; E->use_graph = 0; return nullptr;
-    }
-    g.period = n;
-    E->graphs.push_back(g);
-    return &E->graphs.back();
+    E->d.stress_fold = 0;
 }
 
 extern "C" {
@@ -999,22 +940,8 @@ int beom_step(beom_handle E, int tstp_first, int nsteps, double tres, double dtd
     if (E->P.flag_nudging && E->P.mcbc < 0.5 && !E->obc && !E->obc_set) { set_err(errm, errm_len, "beom_step: mcbc = 0 with nudging needs beom_set_open_boundaries (no_gradient_obc, private_mod.f95:2613-2679)"); return -6; }
     if (E->lid && !E->lid_ready) { set_err(errm, errm_len, "beom_step: rgld = 1 needs beom_set_rigid_lid (the Poisson operators Ow, Os, Osum_ and the lid pressure, private_mod.f95:505-563)"); return -6; }
     HIP_TRY(hipSetDevice(E->device));
-    const int end = tstp_first + nsteps;
-    int tstp = tstp_first;
-    while (tstp < end) {
-        // enough steps ahead to pay for a capture (a few ms), and every one of them replayable
-        if (end - tstp >= 48 && graph_step_ok(E, tstp, tres, dtd8, dt_r, rsta, n_3d) &&
-            graph_step_ok(E, end - 1, tres, dtd8, dt_r, rsta, n_3d)) {
-            beom_engine::StepGraph *g = graph_for(E, tstp, tres, dtd8, dt_r, rsta, n_3d);
-            if (g) {
-                while (end - tstp >= g->period) {
-                    HIP_TRY(hipGraphLaunch(g->exec, E->stream));
-                    tstp += g->period; E->graph_steps += g->period;
-                }
-            }
-        }
-        if (tstp < end) { one_step(E, tstp, step_scalars(E, tstp, tres, dtd8, dt_r, rsta, n_3d)); ++tstp; ++E->eager_steps; }
-    }
+    for (int tstp = tstp_first; tstp < tstp_first + nsteps; ++tstp)
+        one_step(E, tstp, step_scalars(E, tstp, tres, dtd8, dt_r, rsta, n_3d));
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1058,14 +985,22 @@ int beom_profile_steps(beom_handle E, int tstp_first, int nsteps, double tres, d
 }
 
 // ---- split step for the ghost-row exchange overlap ------------------------
-// phase 1: every sweep on the rows whose results cannot depend on ghost rows refreshed by the
-//          exchange still in flight (the dependency front advances <= 1 row per sweep);
-// phase 2: the remaining rows next to the ghost zones, then the pointer rotations.
-// G = 4 ghost rows per neighbour (beom_amd/slab.py).  Only for the fused dense path on steps
-// > 3 without a stress update; returns -20 when the caller must use beom_step instead.
+// A band's step in three parts, so that the rows the neighbours are waiting for are finished, packed and on their way
+// while the bulk of the momentum sweep still runs — "boundary first" within ONE step; every part sees ghost rows that
+// have landed, nothing in flight is read:
+//   part 1: everything up to the momentum sweeps on all rows (stress, rebuild of steps 1-3, update_h, Montgomery + Leith);
+//   part 2: the fused u+v sweep on the strips next to the ghost zones (rows 1..8 and M-7..M: the ghost rows and the
+//           outermost owned rows, which are what beom_pack_rows sends) — the caller enqueues it on ANOTHER stream,
+//           behind part 1, followed by pack -> transport -> unpack;
+//   part 3: the same sweep on the rows in between, on the handle's usual stream, then the pointer rotations.
+// The fused sweep writes out of place and every workgroup evaluates its own halo, so parts 2 and 3 may run side by side;
+// the unpack writes rows 1..4 / M-3..M, part 3 reads no row below 6 / above M-5.  G = 4 ghost rows per neighbour
+// (beom_amd/slab.py).  Needs the fused u+v sweep and no open-boundary pass; returns -20 when the caller must use
+// beom_step instead (call part 1 first: it decides).
 static void set_rows(DevView &d, int n, int lo0, int hi0, int lo1 = 1, int hi1 = 0) {
     d.nstrip = n; d.jlo0 = lo0; d.jhi0 = hi0; d.jlo1 = lo1; d.jhi1 = hi1;
 }
+constexpr int kEdgeRows = 8;           // ghost rows + the owned rows a neighbour receives
 
 int beom_step_phase(beom_handle E, int tstp, double tres, double dtd8, double dt_r, double rsta, int n_3d,
                     int phase, char *errm, int errm_len) {
@@ -1074,11 +1009,7 @@ int beom_step_phase(beom_handle E, int tstp, double tres, double dtd8, double dt
     DevView &d = E->d;
     const StepScalars s = step_scalars(E, tstp, tres, dtd8, dt_r, rsta, n_3d);
     const bool south = d.slab && d.joff > 0, north = d.slab && d.joff + d.M < d.Mg;
-    // Montgomery+Leith in one sweep, or — when no viscosity refresh is due (dvis <= 1e-3, svis = 0) — the
-    // plain Montgomery sweep; the momentum sweeps must be the fused pair (out-of-place writes)
-    const bool visc_due = (E->P.dvis > 1.e-3 && s.upst) || E->P.svis > 0.0;
-    if (!(s.fused_uv && (s.fused || !visc_due)) || s.first3 || (s.stress && (E->wind || E->bot || E->top)) ||
-        !(south || north) || d.M < 32 || (phase != 1 && phase != 2) || E->obc) {
+    if (!s.fused_uv || !(south || north) || d.M < 4 * kEdgeRows || phase < 1 || phase > 3 || E->obc || E->lid) {
         set_err(errm, errm_len, "beom_step_phase: split step not available for this step/configuration");
         return -20;
     }
@@ -1086,69 +1017,38 @@ int beom_step_phase(beom_handle E, int tstp, double tres, double dtd8, double dt
     const bool u_first = tstp % 2 == 0;
     StepTimer *T = (E->timer && tstp % E->timer->stride == 0) ? E->timer : nullptr;
     if (T) T->st = E->stream;
-    // Phase 2 may be enqueued on ANOTHER stream than phase 1 (beom_multi: the edge strips then run inside the interior
-    // sweeps instead of after them).  Its sweeps read what phase 1's sweep of the kind before wrote next to the strips
-    // (Montgomery of rows 1..9 reads the thickness of row 10; the momentum sweep of rows 1..10 the potentials of row 11):
-    // two events say when.  Phase 1 reads nothing phase 2 writes.
-    if (!E->ev_h1) { HIP_TRY(hipEventCreateWithFlags(&E->ev_h1, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&E->ev_mv1, hipEventDisableTiming)); }
-    if (phase == 1) {
-        set_rows(d, 1, south ? 9 : 1, north ? M - 8 : M);
+    E->d.stress_fold = stress_folds(E, s) ? 1 : 0;
+    if (phase == 1) {                                                  // one_step up to the momentum sweeps
+        if (s.stress && !E->d.stress_fold) launch_stress(E);
+        if (s.first3) launch_rebuild(E);                               // :2166-2177
         if (T) T->begin(0);
-        launch_h(E, s.gene, s.ramp, s.ctim, false);
+        launch_h(E, s.gene, s.ramp, s.ctim);                           // :2181,2259
+        const bool leith = E->P.dvis > 1.e-3 && s.upst;
+        if (T) { T->end(); T->begin(s.fused ? 5 : 1); }
+        E->split_prod = s.fused && launch_mont_visc(E, true, leith, leith && s.n_3d > 1);
+        if (!E->split_prod) launch_mont(E, 0);
         if (T) T->end();
-        HIP_TRY(hipEventRecord(E->ev_h1, E->stream));
-        if (s.muv) {
-            if (T) T->begin(5);
-            set_rows(d, 1, south ? 10 : 1, north ? M - 9 : M);
-            launch_muv_edges(E, E->P.dvis > 1.e-3 && s.upst);
-            HIP_TRY(hipEventRecord(E->ev_mv1, E->stream));
-            if (T) { T->end(); T->begin(7); }
-            set_rows(d, 1, south ? 11 : 1, north ? M - 10 : M);
-            launch_muv(E, u_first, E->P.dvis > 1.e-3 && s.upst, s.gene, s.ramp, s.ctim, false);
-            if (T) T->end();
-        } else {
-            if (T) T->begin(s.fused ? 5 : 1);
-            set_rows(d, 1, south ? 10 : 1, north ? M - 9 : M);
-            if (s.fused) launch_mont_visc(E, true, E->P.dvis > 1.e-3 && s.upst, E->P.dvis > 1.e-3 && s.upst && s.n_3d > 1); else launch_mont(E, 0);
-            HIP_TRY(hipEventRecord(E->ev_mv1, E->stream));
-            if (T) { T->end(); T->begin(6); }
-            set_rows(d, 1, south ? 11 : 1, north ? M - 10 : M);
-            launch_uv_fused(E, u_first, s.fused, s.gene, s.ramp, s.ctim, false);
+        if (!E->split_prod && (s.first3 || (E->P.dvis > 1.e-3 && s.upst) || E->P.svis > 0.0)) {     // :2188,2268
+            if (T) T->begin(2);
+            launch_visc(E, 0);
             if (T) T->end();
         }
+    } else if (phase == 2) {
+        // a side without a neighbour has no strip (its rows belong to part 3)
+        if (south && north) set_rows(d, 2, 1, kEdgeRows, M - kEdgeRows + 1, M);
+        else if (south) set_rows(d, 1, 1, kEdgeRows);
+        else set_rows(d, 1, M - kEdgeRows + 1, M);
+        if (T) T->begin(6);
+        launch_uv_fused(E, u_first, E->split_prod, s.gene, s.ramp, s.ctim, false);
+        if (T) T->end();
     } else {
-        // edge strips; a side without a neighbour has no strip (its rows were done in phase 1)
-        auto strips = [&](int depth) {
-            if (south && north) set_rows(d, 2, 1, depth, M - depth + 1, M);
-            else if (south) set_rows(d, 1, 1, depth);
-            else set_rows(d, 1, M - depth + 1, M);
-        };
-        strips(8);
-        if (T) T->begin(0);
-        launch_h(E, s.gene, s.ramp, s.ctim, true);
+        set_rows(d, 1, south ? kEdgeRows + 1 : 1, north ? M - kEdgeRows : M);
+        if (T) T->begin(6);
+        launch_uv_fused(E, u_first, E->split_prod, s.gene, s.ramp, s.ctim, true);
         if (T) T->end();
-        HIP_TRY(hipStreamWaitEvent(E->stream, E->ev_h1, 0));
-        if (s.muv) {
-            if (T) T->begin(5);
-            strips(9);
-            launch_muv_edges(E, E->P.dvis > 1.e-3 && s.upst);
-            HIP_TRY(hipStreamWaitEvent(E->stream, E->ev_mv1, 0));
-            if (T) { T->end(); T->begin(7); }
-            strips(10);
-            launch_muv(E, u_first, E->P.dvis > 1.e-3 && s.upst, s.gene, s.ramp, s.ctim, true);
-            if (T) T->end();
-        } else {
-            if (T) T->begin(s.fused ? 5 : 1);
-            strips(9);
-            if (s.fused) launch_mont_visc(E, true, E->P.dvis > 1.e-3 && s.upst, E->P.dvis > 1.e-3 && s.upst && s.n_3d > 1); else launch_mont(E, 0);
-            HIP_TRY(hipStreamWaitEvent(E->stream, E->ev_mv1, 0));
-            if (T) { T->end(); T->begin(6); }
-            strips(10);
-            launch_uv_fused(E, u_first, s.fused, s.gene, s.ramp, s.ctim, true);
-            if (T) T->end();
-        }
     }
     set_rows(d, 1, 1, M);
+    d.stress_fold = 0;
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1252,7 +1152,6 @@ int beom_set_open_boundaries(beom_handle E, int nseg, const int32_t *segm, char 
     if (!E || nseg < 0 || (nseg > 0 && !segm)) { set_err(errm, errm_len, "beom_set_open_boundaries: bad arguments"); return -1; }
     HIP_TRY(hipSetDevice(E->device));
     if (nseg == 0) {                    // (a band of a frame whose segments all lie in other bands)
-        graphs_clear(E);
         E->d.segm = nullptr; E->d.nseg = 0; E->obc = false; E->obc_set = true;
         return 0;
     }
@@ -1295,7 +1194,6 @@ int beom_set_open_boundaries(beom_handle E, int nseg, const int32_t *segm, char 
     HIP_TRY(hipMalloc((void **)&dev, (size_t)nseg * 18 * sizeof(int32_t)));
     E->allocs.push_back(dev);
     HIP_TRY(hipMemcpy(dev, sg.data(), (size_t)nseg * 18 * sizeof(int32_t), hipMemcpyHostToDevice));
-    graphs_clear(E);
     E->d.segm = dev;
     E->d.nseg = nseg;
     E->obc = E->P.flag_nudging && E->P.mcbc < 0.5;
@@ -1303,22 +1201,13 @@ int beom_set_open_boundaries(beom_handle E, int nseg, const int32_t *segm, char 
     return 0;
 }
 
-int beom_graph_stats(beom_handle E, long long *graph_steps, long long *eager_steps) {
-    if (!E) return -1;
-    if (graph_steps) *graph_steps = E->graph_steps;
-    if (eager_steps) *eager_steps = E->eager_steps;
-    return 0;
-}
-
 int beom_set_option(beom_handle E, const char *name, int value) {
     if (!E || !name) return -1;
-    graphs_clear(E);                   // launches baked into a graph may no longer be the ones this option selects
     if (!strcmp(name, "fuse")) { E->fuse = value != 0; E->fuse_uv = value != 0; }
     else if (!strcmp(name, "fuse_mont_visc")) E->fuse = value != 0 && !E->lid;      // (a lid handle keeps the separate sweeps)
     else if (!strcmp(name, "fuse_uv")) E->fuse_uv = value != 0 && !E->lid;
-    else if (!strcmp(name, "fuse_muv")) E->fuse_muv = value != 0 && !E->lid;
-    else if (!strcmp(name, "graph")) E->use_graph = value;
     else if (!strcmp(name, "keep_diag")) E->d.keep_diag = value != 0;
+    else if (!strcmp(name, "fold_stress")) E->fold_stress = value != 0;
     else if (!strcmp(name, "profile_stride")) E->profile_stride = value > 0 ? value : 1;
     else if (!strcmp(name, "lean_d2h")) E->lean_d2h = value != 0;
     else if (!strcmp(name, "lean_visc")) E->lean_visc = value != 0;

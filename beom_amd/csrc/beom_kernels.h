@@ -287,16 +287,6 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_update_mont_all(DevView d) {
 #define UV_BLOCK (64 * UV_WAVES)
 #define UV_TY (UV_WAVES * UV_Q)
 static constexpr int kUvBlock = UV_BLOCK;      // (for the launch code: the macros hold the LAST geometry included)
-// tile (x0, y0) and everything its fused evaluation reads (3 cells around it) inside the wet interior
-__device__ __forceinline__ bool muv_tile_interior(const DevView &d, int x0, int y0) {
-    return x0 - 2 >= 2 && x0 + UV_TX + 1 <= d.L - 2 && y0 - 2 >= 2 && y0 + UV_TY + 1 <= d.M - 2
-           && y0 - 2 + d.joff >= 2 && y0 + UV_TY + 1 + d.joff <= d.Mg - 2 && !d.embedded;      // (frames with land: the two fused sweeps)
-}
-// every tile around (and including) this one takes the fused path: nobody reads mont, pvor, pcd, qlr, d2h of it from memory
-__device__ __forceinline__ bool muv_tile_deep(const DevView &d, int x0, int y0) {
-    return muv_tile_interior(d, x0 - UV_TX, y0 - UV_TY) && muv_tile_interior(d, x0 + UV_TX, y0 + UV_TY);
-}
-
 #define MV_LDX (MV_TX + 2 + 1)          // +1 pad column
 #define MV_LDY (MV_TY + 2)
 
@@ -543,9 +533,8 @@ __global__ __launch_bounds__(BEOM_BLOCK) MV_OCC_ATTR void k_mont_visc(DevView d)
     if (deep && d.embedded)           // all nine k_uv_fused tiles around this one take the staged interior path
         for (int dy = -1; dy <= 1; ++dy)
             for (int dx = -1; dx <= 1; ++dx) deep = deep && tile_regular(d, x0 + dx * UV_TX, uy0 + dy * UV_TY, UV_TY);
-    if (d.only_shallow && muv_tile_deep(d, x0, uy0)) return;  // the fused Montgomery + momentum sweep follows: nobody reads this tile's results
-    const bool wr_d2h = d.only_shallow || !(d.lean_d2h && deep);
-    const bool wr_prod = d.only_shallow || !(d.zero_visc && deep);   // zero viscosity: interior workgroups of k_uv_fused skip the term
+    const bool wr_d2h = !(d.lean_d2h && deep);
+    const bool wr_prod = !(d.zero_visc && deep);   // zero viscosity: interior workgroups of k_uv_fused skip the term
     if (interior) body_mont_visc<NL, true, LEITH>(d, x0, y0, wr_d2h, wr_prod, (double (*)[MV_LDY][MV_LDX])s_rv, (double (*)[MV_LDY][MV_LDX])s_dv, s_hh);
     else body_mont_visc<NL, false, LEITH>(d, x0, y0, wr_d2h, wr_prod, (double (*)[MV_LDY][MV_LDX])s_rv, (double (*)[MV_LDY][MV_LDX])s_dv, s_hh);
 }
@@ -656,6 +645,22 @@ struct ShLds {                                       // field order in the stage
     template <bool X> __device__ __forceinline__ double d2h_b() const { return d2h_at(r + 1 + RB, c + 1 + CB); }
 };
 
+// distribute_stress folded into the momentum sweep (DevView::stress_fold: ocrp = 0, so the drag layer is the bottom resp.
+// the top layer itself and its fraction is 1 at the cell and at its W / S neighbour): tb3d | tu3d (ipnt, direction, ilay)
+// as :2015-2071 | :2075-2146 form it, from the velocities BEFORE this sweep (d.u, d.v: the fused sweep writes out of place).
+template <bool XDIR, bool TOP, class C>
+__device__ __forceinline__ double fold_drag(const C &c, const DevView &d, int ilay, double vel_self) {
+    const int ipnt = c.ipnt;
+    double other;                                  // the other component averaged to this point (:2019-2026, 2034-2041)
+    if (XDIR) other = 0.25 * LL(d.v, ipnt, ilay) + 0.25 * LL(d.v, c.template nb<3>(), ilay) + 0.25 * LL(d.v, c.template nb<4>(), ilay)
+                      + 0.25 * LL(d.v, c.template nb<5>(), ilay);
+    else      other = 0.25 * LL(d.u, ipnt, ilay) + 0.25 * LL(d.u, c.template nb<1>(), ilay) + 0.25 * LL(d.u, c.template nb<7>(), ilay)
+                      + 0.25 * LL(d.u, c.template nb<8>(), ilay);
+    const double drg = TOP ? d.tdrg : d.bdrg;
+    const double tau = vel_self * drg * (TOP ? d.rho_top : d.rho_bot) * (d.qdrg * sqrt(vel_self * vel_self + other * other) + 1.0 - d.qdrg);   // (rhon of layer 1 | nlay: no indexing into the kernel argument)
+    return tau * 0.5 * (1.0 + 1.0);
+}
+
 template <bool XDIR, bool PROD, bool STORE, class C, class SH>
 __device__ __forceinline__ double uv_core(const C &c, const DevView &d, int ilay, double gene, double ramp,
                                           double ctim, int copy_hist, const UVio &io,
@@ -685,7 +690,22 @@ __device__ __forceinline__ double uv_core(const C &c, const DevView &d, int ilay
     double rhsi = dmd4 * (1.0 - gene);
     if (XDIR) rhsi = rhsi + 0.25 * pv0 * (q0 + qb) + 0.25 * pva * (qa + qd);
     else      rhsi = rhsi - 0.25 * pv0 * (q0 + qb) - 0.25 * pva * (qa + qd);
-    if (d.has_stress) {
+    if (d.stress_fold) {
+        // distribute_stress (:1921-2149) inside the sweep — ocrp = 0, a refresh on every step: the fractions are 1 in the top
+        // layer (wind :1953, top drag :1999) resp. the bottom layer (:1977) and 0 elsewhere, so tt3d = taus there, tb3d / tu3d =
+        // the drag at this point from the (old) velocities of that layer, by the reference's own operations.  In every other
+        // layer all three terms are +-0 and the sum that follows (+ bodf, or + (+0)) hides their signs: nothing to do.
+        const bool lay_t = ilay == 1, lay_b = ilay == d.nlay;
+        if ((lay_t && (d.has_wind || d.has_top)) || (lay_b && d.has_bot)) {
+            const double i__h = 1.0 / (hcen + 1.0 - mask);
+            if (lay_t && d.has_wind) {
+                const double tauw = 0.5 * (d.taus_cells[cb + d.n1 * (ID - 1)] + d.taus_cells[ipnt + d.n1 * (ID - 1)]) * ramp;
+                rhsi = rhsi + tauw * i_r0 * i__h;
+            } else rhsi = rhsi + 0.0;
+            if (lay_b && d.has_bot) rhsi = rhsi - fold_drag<XDIR, false>(c, d, ilay, vold) * i_r0 * i__h;
+            if (lay_t && d.has_top) rhsi = rhsi - fold_drag<XDIR, true>(c, d, ilay, vold) * i_r0 * i__h;
+        }
+    } else if (d.has_stress) {
         const double i__h = 1.0 / (hcen + 1.0 - mask);
         const double tauw = 0.5 * (T3_(d.tt3d, cb, ID, ilay) + T3_(d.tt3d, ipnt, ID, ilay)) * ramp;
         rhsi = rhsi + tauw * i_r0 * i__h;
@@ -744,7 +764,12 @@ __device__ __forceinline__ double uv_core(const C &c, const DevView &d, int ilay
     if (f_ng != 0.0 || vold == 0.0) {
         const double i__hh = 1.0 / (hcen + 1.0 - mask);
         double vfor = FNUD_(ipnt, ilay, IV);
-        if (d.has_stress) {
+        if (d.stress_fold) {                   // tt3d = taus * fraction (1 in the top layer, 0 below), formed here (see above)
+            const double lt = ilay == 1 ? 1.0 : 0.0;
+            const double t0 = d.has_wind ? d.taus_cells[ipnt + d.n1 * (IO - 1)] * lt : 0.0, tb_ = d.has_wind ? d.taus_cells[cb + d.n1 * (IO - 1)] * lt : 0.0;
+            const double ek = 0.5 * (t0 + tb_) * i_r1 * d.invf * i__hh * ramp;
+            vfor = XDIR ? vfor + ek : vfor - ek;
+        } else if (d.has_stress) {
             const double ek = 0.5 * (T3_(d.tt3d, ipnt, IO, ilay) + T3_(d.tt3d, cb, IO, ilay))
                               * i_r1 * d.invf * i__hh * ramp;
             vfor = XDIR ? vfor + ek : vfor - ek;
@@ -1204,229 +1229,6 @@ __global__ __launch_bounds__(UV_BLOCK) UV_OCC_ATTR void k_uv_fused(DevView d, do
 static inline dim3 uv_fused_grid(const DevView &d) {
     return dim3(TileMap(d, UV_TX, UV_TY).blocks(), (unsigned)d.nlay, 1);
 }
-
-// ---- the Montgomery + Leith sweep folded INTO the momentum sweep (dense frames, production path) ------
-//      update_mont_rvor_pvor_dive_kine (:2318-2439), update_viscosity (:2441-2502), update_u and update_v
-//      (:1422-1591) of one time step as ONE launch: a workgroup derives mont, pvor and the viscous products
-//      v_cc*dive, v_ll*rvor on its 64 x 8 tile plus the ring both momentum updates read — from u, v and the
-//      new hlay — straight into the LDS image the staged momentum sweep used to LOAD from global memory.
-//      Those four arrays are then neither written (k_mont_visc: 4 words per cell-layer) nor read back
-//      (k_uv_fused: 4 words), and u, v, hlay are read once per step instead of twice: 45 algorithmic words
-//      of the reference's four sweeps become 10 in + 6 out.  The price is arithmetic on the rings: rvor and
-//      dive on tile + 2 cells (816 cells per 512), Leith and Montgomery on tile + 1 (660).
-//      A thread walks all NL layers (the Montgomery potential sums the column, :2357-2375).
-//      Only workgroups whose whole stencil (tile + 3) lies in the wet interior take this path; the others
-//      run the momentum sweep from global arrays as before, which k_mont_visc still fills for the tiles
-//      next to them (DevView::only_shallow).
-#define MUV_R2ROWS (UV_TY + 4)                    // rows y0-2 .. y0+TY+1
-#define MUV_R2COLS (UV_TX + 4)                    // cols x0-2 .. x0+TX+1
-#define MUV_R2 (MUV_R2ROWS * MUV_R2COLS)
-#define MUV_NIT ((MUV_R2 + UV_BLOCK - 1) / UV_BLOCK)
-static_assert(MUV_R2ROWS == UV_HROWS && MUV_R2COLS == UV_HLDX, "the rvor/dive region is the widened hlay stage");
-
-template <bool FIRST_X, bool LEITH, bool ZV>
-__device__ __forceinline__ void body_muv(const DevView &d, int x0, int y0, double gene, double ramp, double ctim,
-                                         double (*s_h)[UV_LDX], UVstage *s_f, double (*s_hl)[UV_HLDX],
-                                         double (*s_rv)[MUV_R2COLS + 1], double (*s_dv)[MUV_R2COLS + 1],
-                                         const double *s_rho, const double *s_irn) {
-    const int NL = d.nlay;
-    const int tid = threadIdx.x;
-    const int lx = tid & 63, wy = tid >> 6;
-    const int i = x0 + lx;
-    constexpr int ROFF = FIRST_X ? 1 : 0, COFF = FIRST_X ? 0 : 1;      // s_h coordinates as in body_uv_fused
-    const double i_gr = d.i_gr, i_ns = d.i_ns;
-    // ---- cells of the widened region this thread evaluates rvor, dive (and, inside the one-cell ring, mont ...) for
-    // (registers are the scarce resource here: per-cell statics are re-fetched per layer from L1, and the u, v
-    // values are folded into rvor, dive and the kinetic term as soon as they have arrived)
-    // The layer loop is NOT unrolled (one instantiation serves every layer count, and nothing of one layer is
-    // scheduled into the previous one): the thicknesses of the layers above are re-read from L1/L2 where the
-    // Montgomery potential sums them, and the densities come from LDS (a dynamic index into a kernel argument
-    // would send the whole DevView to scratch).
-    // What a region cell needs later (rvor, dive, the kinetic term, its thickness) is parked in LDS rather than in
-    // registers: the momentum updates need ~120 VGPRs of their own, and occupancy is what hides the latency here.
-    int r2[MUV_NIT], c2[MUV_NIT], ip2[MUV_NIT];
-    bool in2[MUV_NIT], in1[MUV_NIT];
-    double hcol[MUV_NIT];
-#pragma unroll
-    for (int k = 0; k < MUV_NIT; ++k) {
-        const int idx = tid + k * UV_BLOCK;
-        in2[k] = idx < MUV_R2;
-        const int idc = in2[k] ? idx : tid;               // clamped: harmless loads, no stores
-        r2[k] = idc / MUV_R2COLS; c2[k] = idc - r2[k] * MUV_R2COLS;
-        in1[k] = in2[k] && r2[k] >= 1 && r2[k] <= UV_TY + 2 && c2[k] >= 1 && c2[k] <= UV_TX + 2;
-        ip2[k] = (x0 - 2 + c2[k]) + (y0 - 3 + r2[k]) * d.P;
-        hcol[k] = 0.0;
-    }
-    for (int l = 0; l < NL; ++l) {
-#pragma unroll
-        for (int k = 0; k < MUV_NIT; ++k) hcol[k] = hcol[k] + LL(d.hlay, ip2[k], l + 1);       // :2365-2371
-    }
-    // ---- own cells of the momentum updates and the ring cell of the first one (as in body_uv_fused_staged)
-    CellDenseT<true> c[UV_Q];
-    bool wr[UV_Q];
-#pragma unroll
-    for (int q = 0; q < UV_Q; ++q) {
-        const int j = y0 + wy + UV_WAVES * q;
-        wr[q] = row_selected(d, j);                  // cells outside the strips are evaluated, not stored
-        c[q].set_cell(d, i, j);
-    }
-    int rr1 = -1, cc1 = -1;
-    if (tid <= UV_TX) { rr1 = FIRST_X ? 0 : UV_TY; cc1 = tid; }
-    else if (tid <= UV_TX + UV_TY) { rr1 = (tid - UV_TX - 1) + ROFF; cc1 = FIRST_X ? UV_TX : 0; }
-    const int ra = rr1 >= 0 ? (FIRST_X ? x0 : x0 - 1) + cc1 : i;
-    const int rb = rr1 >= 0 ? (FIRST_X ? y0 - 1 : y0) + rr1 : y0 + wy;
-    CellDenseT<true> hc;
-    hc.set_cell(d, ra, rb);
-    const double hs2 = 2.0 * d.hsal;
-
-#pragma nounroll
-    for (int l = 0; l < NL; ++l) {
-        const int ilay = l + 1;
-        // The cell indices are made opaque once per layer: otherwise every address of the loop body (some sixty
-        // 64-bit pointers per lane) is hoisted out of the loop and kept in VGPRs across it (256 VGPRs + spills).
-#pragma unroll
-        for (int k = 0; k < MUV_NIT; ++k) asm volatile("" : "+v"(ip2[k]));
-#pragma unroll
-        for (int q = 0; q < UV_Q; ++q) asm volatile("" : "+v"(c[q].ipnt));
-        asm volatile("" : "+v"(hc.ipnt));
-        // ---- u, v around the region cells -> rvor, dive (interior form: mkpe = 1), the kinetic term; the new thickness
-        {
-            double w[MUV_NIT][6], h0v[MUV_NIT];
-#pragma unroll
-            for (int k = 0; k < MUV_NIT; ++k) {
-                const int ip = ip2[k];
-                h0v[k] = LL(d.hlay, ip, ilay);
-                w[k][0] = LL(d.u, ip, ilay); w[k][1] = LL(d.u, ip + 1, ilay);
-                w[k][2] = LL(d.v, ip, ilay); w[k][3] = LL(d.v, ip + d.P, ilay);
-                w[k][4] = LL(d.v, ip - 1, ilay); w[k][5] = LL(d.u, ip - d.P, ilay);
-            }
-#pragma unroll
-            for (int k = 0; k < MUV_NIT; ++k) {
-                if (!in2[k]) continue;
-                s_rv[r2[k]][c2[k]] = (w[k][2] - w[k][4] - w[k][0] + w[k][5]) * d.i_dl * 1.0;      // (v_bo - v(W) - u_le + u(S)) * mkpe, :2388
-                s_dv[r2[k]][c2[k]] = (w[k][1] - w[k][0] + w[k][3] - w[k][2]) * d.i_dl;            // :2435
-                s_hl[r2[k]][c2[k]] = h0v[k];
-                if (in1[k])            // the kinetic term of mont (:2380-2383): u_ri, u_le, v_to, v_bo; the potential is added below
-                    s_f[0][r2[k] - 1][c2[k] - 1] = 0.25 * d.uadv * i_gr
-                                                   * (w[k][1] * w[k][1] + w[k][0] * w[k][0] + w[k][3] * w[k][3] + w[k][2] * w[k][2]);
-            }
-        }
-        __syncthreads();
-        // the first momentum update's own data: in flight while the stage is filled
-        double pre[UV_Q][8], preR[8];
-#pragma unroll
-        for (int q = 0; q < UV_Q; ++q) uv_pre_load<FIRST_X>(d, c[q], ilay, gene, true, pre[q]);
-        uv_pre_load<FIRST_X>(d, hc, ilay, gene, true, preR);
-        // ---- mont, pvor and the viscous products on tile + ring (:2351-2383, :2421-2433, :2458-2502; masks = 1)
-#pragma unroll
-        for (int k = 0; k < MUV_NIT; ++k) {
-            if (!in1[k]) continue;
-            const int r = r2[k], cx = c2[k], ip = ip2[k];
-            const double mkn = 1.0;
-            const double h0 = s_hl[r][cx];
-            double mpot = -0.0;
-            if (d.ocrp != 0.0) {
-                mpot = h0 + d.hmin * (1.0 - mkn);
-                mpot = powi_dev(d.hsal / mpot, d.nsal - 1);
-                mpot = mpot * (-d.ocrp * i_ns * d.hsal * mkn);
-            }
-            mpot = mpot - (d.has_hto ? d.h_to[ip] : 0.0);
-            const double i_rn = s_irn[l], rho_l = s_rho[l];
-            for (int m = 0; m < l; ++m) mpot = mpot - (rho_l - s_rho[m]) * i_rn * LL(d.hlay, ip, m + 1);
-            if (d.rgld < 0.5) mpot = hcol[k] - d.h_th[ip] + mpot;
-            s_f[0][r - 1][cx - 1] = mpot + s_f[0][r - 1][cx - 1];
-            const double hW = s_hl[r][cx - 1], hS = s_hl[r - 1][cx], h6 = s_hl[r - 1][cx - 1];
-            const double have = h0 + hW + h6 + hS;
-            const double r_bl = s_rv[r][cx], d_cc = s_dv[r][cx];
-            s_f[1][r - 1][cx - 1] = (d.fcor[ip] + r_bl * d.uadv) * 1.0 * (mkn + 1.0 + 1.0 + 1.0) / have;
-            if (!ZV) {
-                double vcc, vll;
-                if (LEITH) {
-                    const double r_br = s_rv[r][cx + 1], r_tr = s_rv[r + 1][cx + 1], r_tl = s_rv[r + 1][cx],
-                                 rbll = s_rv[r][cx - 1], rbbl = s_rv[r - 1][cx];
-                    const double d_ri = s_dv[r][cx + 1], d_to = s_dv[r + 1][cx], d_le = s_dv[r][cx - 1],
-                                 d_bl = s_dv[r - 1][cx - 1], d_bo = s_dv[r - 1][cx];
-                    double a = (r_br - r_bl) * (r_br - r_bl) + (r_bl - rbll) * (r_bl - rbll)
-                             + (r_tl - r_bl) * (r_tl - r_bl) + (r_bl - rbbl) * (r_bl - rbbl)
-                             + (d_cc - d_le) * (d_cc - d_le) + (d_bo - d_bl) * (d_bo - d_bl)
-                             + (d_cc - d_bo) * (d_cc - d_bo) + (d_le - d_bl) * (d_le - d_bl);
-                    vll = sqrt(a) * d.dvis * d.dl * d.dl + d.bvis;
-                    double b = (r_br - r_bl) * (r_br - r_bl) + (r_tr - r_tl) * (r_tr - r_tl)
-                             + (r_tl - r_bl) * (r_tl - r_bl) + (r_tr - r_br) * (r_tr - r_br)
-                             + (d_ri - d_cc) * (d_ri - d_cc) + (d_cc - d_le) * (d_cc - d_le)
-                             + (d_to - d_cc) * (d_to - d_cc) + (d_cc - d_bo) * (d_cc - d_bo);
-                    vcc = sqrt(b) * d.dvis * d.dl * d.dl + d.bvis;
-                } else {
-                    vcc = LL(d.v_cc, ip, ilay); vll = LL(d.v_ll, ip, ilay);
-                }
-                s_f[2][r - 1][cx - 1] = vcc * d_cc;
-                s_f[3][r - 1][cx - 1] = vll * r_bl;
-            }
-            __builtin_amdgcn_sched_barrier(0);      // one cell at a time: hoisting all four cells' LDS reads costs ~100 VGPRs
-        }
-        __syncthreads();
-        // ---- the two momentum updates from the stage (= body_uv_fused_staged after its stage barrier)
-        double pre2[UV_Q][8];
-#pragma unroll
-        for (int q = 0; q < UV_Q; ++q) uv_pre_load<!FIRST_X>(d, c[q], ilay, gene, false, pre2[q]);
-#pragma unroll
-        for (int q = 0; q < UV_Q; ++q) {
-            const int r = wy + UV_WAVES * q;
-            const ShLds<FIRST_X> sh{s_f, s_hl, r + 1, lx + 1, d.ocrp, hs2};
-            s_h[r + ROFF][lx + COFF] = uv_first_eval<FIRST_X, true, true, true>(d, c[q], ilay, gene, ramp, ctim, sh, wr[q], pre[q], ZV);
-        }
-        if (rr1 >= 0) {
-            const ShLds<FIRST_X> sh{s_f, s_hl, rb - (y0 - 1), ra - (x0 - 1), d.ocrp, hs2};
-            s_h[rr1][cc1] = uv_first_eval<FIRST_X, true, false, true>(d, hc, ilay, gene, ramp, ctim, sh, true, preR, ZV);
-        }
-        __syncthreads();
-        double *const *dm = FIRST_X ? d.dmy : d.dmx;
-        const UVio io{FIRST_X ? d.v : d.u, FIRST_X ? d.v_alt : d.u_alt, FIRST_X ? d.hv_alt : d.hu_alt,
-                      dm[0], dm[1], dm[2], dm[0]};
-#pragma unroll
-        for (int q = 0; q < UV_Q; ++q) {
-            if (!wr[q]) continue;
-            const int r = wy + UV_WAVES * q;
-            double q0, qb, qa, qd;
-            if (FIRST_X) { q0 = s_h[r + 1][lx]; qb = s_h[r][lx]; qa = s_h[r + 1][lx + 1]; qd = s_h[r][lx + 1]; }
-            else         { q0 = s_h[r][lx + 1]; qb = s_h[r][lx]; qa = s_h[r + 1][lx + 1]; qd = s_h[r + 1][lx]; }
-            const ShLds<!FIRST_X> sh{s_f, s_hl, r + 1, lx + 1, d.ocrp, hs2};
-            uv_core<!FIRST_X, true, true>(c[q], d, ilay, gene, ramp, ctim, 0, io, q0, qb, qa, qd, sh, true, pre2[q], ZV);
-        }
-        if (l + 1 < NL) __syncthreads();      // the stage is rebuilt for the next layer
-    }
-}
-
-template <bool FIRST_X, bool LEITH, bool ZV>
-__global__ __launch_bounds__(UV_BLOCK, 2) void k_muv(DevView d, double gene, double ramp, double ctim) {
-    __shared__ double s_rho[BEOM_MAX_LAYERS], s_irn[BEOM_MAX_LAYERS];
-    __shared__ double s_h[UV_TY + 1][UV_LDX];
-    __shared__ UVstage s_f[ZV ? 2 : 4];
-    __shared__ double s_hl[UV_HROWS][UV_HLDX];
-    __shared__ double s_rv[MUV_R2ROWS][MUV_R2COLS + 1];
-    __shared__ double s_dv[MUV_R2ROWS][MUV_R2COLS + 1];
-    const TileMap tm(d, UV_TX, UV_TY);
-    int ty, ch;
-    if (!tm.locate(blockIdx.x, ty, ch)) return;
-    const int x0 = ch * UV_TX + 1, y0 = ty * UV_TY + 1;
-    if (muv_tile_interior(d, x0, y0)) {
-#pragma unroll
-        for (int q = 0; q < BEOM_MAX_LAYERS; ++q)         // static indices into the kernel argument, one lane each
-            if ((int)threadIdx.x == q) { s_rho[q] = d.rhon[q]; s_irn[q] = d.i_rn[q]; }
-        __syncthreads();
-        body_muv<FIRST_X, LEITH, ZV>(d, x0, y0, gene, ramp, ctim, s_h, s_f, s_hl, s_rv, s_dv, s_rho, s_irn);
-        return;
-    }
-    // the frame's edge tiles: the momentum sweep from the arrays k_mont_visc stored for them, layer by layer
-    const bool interior = x0 - 1 >= 2 && x0 + UV_TX <= d.L - 2 && y0 - 1 >= 2 && y0 + UV_TY <= d.M - 2
-                          && y0 - 1 + d.joff >= 2 && y0 + UV_TY + d.joff <= d.Mg - 2 && tile_regular(d, x0, y0, UV_TY);
-    for (int ilay = 1; ilay <= d.nlay; ++ilay) {
-        if (interior) body_uv_fused<FIRST_X, true, true>(d, x0, y0, ilay, gene, ramp, ctim, s_h);
-        else body_uv_fused<FIRST_X, true, false>(d, x0, y0, ilay, gene, ramp, ctim, s_h);
-        __syncthreads();
-    }
-}
-static inline dim3 muv_grid(const DevView &d) { return dim3(TileMap(d, UV_TX, UV_TY).blocks(), 1, 1); }
 
 // ---- distribute_stress, private_mod.f95:1921-2149, as ONE launch --------------------------------------------------
 // The reference forms (a) the layer fractions layt / layb / layu of every cell (:1945-2009), (b) the bottom and top stress at

@@ -1,4 +1,4 @@
-// beom_launch_tiled.h — the launches of the tiled sweeps (k_mont_visc, k_uv_fused, k_muv) out of ONE tile geometry.
+// beom_launch_tiled.h — the launches of the tiled sweeps (k_mont_visc, k_uv_fused) out of ONE tile geometry.
 // beom_engine.hip includes beom_kernels.h twice, in namespace t8 (64 x 8 tiles: frames of many rounds of workgroups)
 // and in namespace t4 (64 x 4 tiles, one row per thread: frames of one or two rounds of workgroups, where a
 // workgroup's lifetime is the step time), and this file once for each: TNS = the namespace, TSUF = the suffix of the names.
@@ -28,14 +28,6 @@ static void TFN(raw_uv_fused)(beom_engine *E, bool first_x, bool prod, bool zv, 
         else if (prod) hipLaunchKernelGGL((TNS::k_uv_fused<false, true>), g, b, 0, E->stream, d, gene, ramp, ctim);
         else hipLaunchKernelGGL((TNS::k_uv_fused<false, false>), g, b, 0, E->stream, d, gene, ramp, ctim);
     }
-}
-static void TFN(raw_muv)(beom_engine *E, bool first_x, bool leith, bool zv, double gene, double ramp, double ctim) {
-    DevView &d = E->d;
-    const dim3 g = TNS::muv_grid(d), b(TNS::kUvBlock);
-#define MUV_GO(fx, le, z) hipLaunchKernelGGL((TNS::k_muv<fx, le, z>), g, b, 0, E->stream, d, gene, ramp, ctim)
-    if (first_x) { if (leith) MUV_GO(true, true, false); else if (zv) MUV_GO(true, false, true); else MUV_GO(true, false, false); }
-    else         { if (leith) MUV_GO(false, true, false); else if (zv) MUV_GO(false, false, true); else MUV_GO(false, false, false); }
-#undef MUV_GO
 }
 #undef TFN
 #undef TFN2

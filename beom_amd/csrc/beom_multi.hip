@@ -330,16 +330,15 @@ struct beom_multi {
     int transport = BEOM_XCHG_PEER;
     bool local_mode = false;       // created from this band's window (beom_multi_create_local)
     bool failed = false;           // a step failed half way: the state is undefined, only destroy is allowed
-    bool overlap = true;           // split steps around the exchange in flight (beom_multi_set_option "overlap")
-    bool edge_stream = true;       // ... with the edge strips on a stream of their own, inside the interior sweeps ("edge_stream")
+    bool overlap = true;           // steps cut boundary first, the exchange inside the interior sweep (beom_multi_set_option "overlap")
     size_t n1g = 0;
     bool land = false;             // a frame with land: bands are packed row ranges of unequal length, on the rectangle ("embedded") form
     std::vector<long long> gst;    // land: first packed cell of every global row j = 1..mm+2
     std::vector<int> dev;
     std::vector<Band> band;
     std::vector<beom_handle> eng;
-    std::vector<hipStream_t> main_s, comm_s, edge_s;   // a band's sweeps | its exchange | the edge strips of its split steps
-    std::vector<hipEvent_t> packed, landed, p1start, p2done;
+    std::vector<hipStream_t> main_s, comm_s;          // a band's sweeps | the edge strips of a cut step and its exchange
+    std::vector<hipEvent_t> packed, landed, p1done;
     std::vector<char> pending;     // an exchange into this band is in flight
     std::vector<double *> send_s, recv_s, send_n, recv_n;   // device buffers on the band's device
     std::vector<nccl_comm> comm;
@@ -352,8 +351,8 @@ struct beom_multi {
     int mini_k = -1;               // local index of band 0, or -1 if band 0 is not here
     hipStream_t mini_s = nullptr;
     double *mini_lo = nullptr, *mini_hi = nullptr;
-    hipEvent_t ev_lo = nullptr, ev_hi = nullptr, ev_free = nullptr;
-    bool lo_packed = false, free_recorded = false;
+    hipEvent_t ev_hi = nullptr, ev_free = nullptr;
+    bool free_recorded = false;
     std::vector<int> mini_rows;
 
     int local_of(int gidx) const { for (int k = 0; k < n; ++k) if (band[k].index == gidx) return k; return -1; }
@@ -372,7 +371,6 @@ void destroy_all(beom_multi *M) {
         (void)hipSetDevice(M->dev[k]);
         if (k < (int)M->main_s.size() && M->main_s[k]) (void)hipStreamSynchronize(M->main_s[k]);
         if (k < (int)M->comm_s.size() && M->comm_s[k]) (void)hipStreamSynchronize(M->comm_s[k]);
-        if (k < (int)M->edge_s.size() && M->edge_s[k]) (void)hipStreamSynchronize(M->edge_s[k]);
     }
     if (M->mini_k >= 0) {
         (void)hipSetDevice(M->dev[M->mini_k]);
@@ -380,7 +378,7 @@ void destroy_all(beom_multi *M) {
         if (M->mini) (void)beom_destroy(M->mini);
         if (M->mini_lo) (void)hipFree(M->mini_lo);
         if (M->mini_hi) (void)hipFree(M->mini_hi);
-        for (hipEvent_t e : {M->ev_lo, M->ev_hi, M->ev_free}) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : {M->ev_hi, M->ev_free}) if (e) (void)hipEventDestroy(e);
         if (M->mini_s) (void)hipStreamDestroy(M->mini_s);
     }
     if (M->shm) { if (M->n > 0) (void)hipSetDevice(M->dev[0]); shm_close(M->shm); M->shm = nullptr; }
@@ -392,9 +390,7 @@ void destroy_all(beom_multi *M) {
             if (k < (int)v->size() && (*v)[k]) (void)hipFree((*v)[k]);
         if (k < (int)M->packed.size() && M->packed[k]) (void)hipEventDestroy(M->packed[k]);
         if (k < (int)M->landed.size() && M->landed[k]) (void)hipEventDestroy(M->landed[k]);
-        if (k < (int)M->p1start.size() && M->p1start[k]) (void)hipEventDestroy(M->p1start[k]);
-        if (k < (int)M->p2done.size() && M->p2done[k]) (void)hipEventDestroy(M->p2done[k]);
-        if (k < (int)M->edge_s.size() && M->edge_s[k]) (void)hipStreamDestroy(M->edge_s[k]);
+        if (k < (int)M->p1done.size() && M->p1done[k]) (void)hipEventDestroy(M->p1done[k]);
         if (k < (int)M->comm_s.size() && M->comm_s[k]) (void)hipStreamDestroy(M->comm_s[k]);
         if (k < (int)M->main_s.size() && M->main_s[k]) (void)hipStreamDestroy(M->main_s[k]);
     }
@@ -512,11 +508,9 @@ int finish_band(beom_multi *M, int k, char *errm, int errm_len) {
     M_HIP(hipSetDevice(M->dev[k]));
     M_HIP(hipStreamCreateWithFlags(&M->main_s[k], hipStreamNonBlocking));
     M_HIP(hipStreamCreateWithFlags(&M->comm_s[k], hipStreamNonBlocking));
-    M_HIP(hipStreamCreateWithFlags(&M->edge_s[k], hipStreamNonBlocking));
     M_HIP(hipEventCreateWithFlags(&M->packed[k], hipEventDisableTiming));
     M_HIP(hipEventCreateWithFlags(&M->landed[k], hipEventDisableTiming));
-    M_HIP(hipEventCreateWithFlags(&M->p1start[k], hipEventDisableTiming));
-    M_HIP(hipEventCreateWithFlags(&M->p2done[k], hipEventDisableTiming));
+    M_HIP(hipEventCreateWithFlags(&M->p1done[k], hipEventDisableTiming));
     if (M->has_s(k)) { M_HIP(hipMalloc((void **)&M->send_s[k], M->xbytes)); M_HIP(hipMalloc((void **)&M->recv_s[k], M->xbytes)); }
     if (M->has_n(k)) { M_HIP(hipMalloc((void **)&M->send_n[k], M->xbytes)); M_HIP(hipMalloc((void **)&M->recv_n[k], M->xbytes)); }
     (void)beom_set_stream(M->eng[k], (void *)M->main_s[k], 0);
@@ -535,7 +529,7 @@ int create_mini(beom_multi *M, const StaticsV &st, char *errm, int errm_len) {
     if (!beom_is_dense(M->mini)) { m_err(errm, errm_len, "beom_multi: the companion frame did not qualify for the dense path"); return -4; }
     M_HIP(hipSetDevice(M->dev[k]));
     M_HIP(hipStreamCreateWithFlags(&M->mini_s, hipStreamNonBlocking));
-    for (hipEvent_t *e : {&M->ev_lo, &M->ev_hi, &M->ev_free}) M_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    for (hipEvent_t *e : {&M->ev_hi, &M->ev_free}) M_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
     const size_t row = (size_t)kFields * M->P.nlay * L * sizeof(double);
     M_HIP(hipMalloc((void **)&M->mini_lo, row * kMiniLo));
     M_HIP(hipMalloc((void **)&M->mini_hi, row * kGhost));
@@ -588,8 +582,8 @@ int init_transport(beom_multi *M, const void *rccl_id, char *errm, int errm_len)
 void size_vectors(beom_multi *M) {
     const int n = M->n;
     M->eng.assign(n, nullptr);
-    M->main_s.assign(n, nullptr); M->comm_s.assign(n, nullptr); M->edge_s.assign(n, nullptr);
-    M->packed.assign(n, nullptr); M->landed.assign(n, nullptr); M->p1start.assign(n, nullptr); M->p2done.assign(n, nullptr);
+    M->main_s.assign(n, nullptr); M->comm_s.assign(n, nullptr);
+    M->packed.assign(n, nullptr); M->landed.assign(n, nullptr); M->p1done.assign(n, nullptr);
     M->pending.assign(n, 0);
     M->send_s.assign(n, nullptr); M->recv_s.assign(n, nullptr);
     M->send_n.assign(n, nullptr); M->recv_n.assign(n, nullptr);
@@ -872,7 +866,7 @@ int beom_multi_stats(beom_multi_handle M, long long *split_band_steps, long long
 int beom_multi_set_option(beom_multi_handle M, const char *name, int value) {
     if (!M || !name) return -1;
     if (!strcmp(name, "overlap")) { M->overlap = value != 0; return 0; }
-    if (!strcmp(name, "edge_stream")) { M->edge_stream = value != 0; return 0; }
+    if (!strcmp(name, "edge_stream")) return 0;       // (an option of the earlier split form; accepted, without effect)
     int rc = 0;
     for (int k = 0; k < M->n && !rc; ++k) rc = beom_set_option(M->eng[k], name, value);
     if (!rc && M->mini) rc = beom_set_option(M->mini, name, value);
@@ -895,7 +889,6 @@ int beom_multi_sync(beom_multi_handle M, char *errm, int errm_len) {
         M_HIP(hipSetDevice(M->dev[k]));
         M_HIP(hipStreamSynchronize(M->main_s[k]));
         if (M->comm_s[k]) M_HIP(hipStreamSynchronize(M->comm_s[k]));
-        if (M->edge_s[k]) M_HIP(hipStreamSynchronize(M->edge_s[k]));
         M->pending[k] = 0;          // whatever was in flight has landed
     }
     if (M->mini) { M_HIP(hipSetDevice(M->dev[M->mini_k])); M_HIP(hipStreamSynchronize(M->mini_s)); }
@@ -926,7 +919,6 @@ int beom_multi_upload_state(beom_multi_handle M, const double *hlay, const doubl
         M_RC(beom_upload_state(k < 0 ? M->mini : M->eng[k], ptr(a.a[0]), ptr(a.a[1]), ptr(a.a[2]), ptr(a.a[3]), ptr(a.a[4]), ptr(a.a[5]),
                                ptr(a.a[6]), ptr(a.a[7]), ptr(a.a[8]), ptr(a.a[9]), ptr(a.a[10]), ptr(a.a[11]), ptr(a.a[12]), errm, errm_len));
     }
-    M->lo_packed = false;
     return 0;
 }
 
@@ -1136,7 +1128,6 @@ int beom_multi_upload_local(beom_multi_handle M, const beom_state *win, const be
         M_RC(beom_upload_state(M->mini, ptr(a.a[0]), ptr(a.a[1]), ptr(a.a[2]), ptr(a.a[3]), ptr(a.a[4]), ptr(a.a[5]), ptr(a.a[6]),
                                ptr(a.a[7]), ptr(a.a[8]), ptr(a.a[9]), ptr(a.a[10]), ptr(a.a[11]), ptr(a.a[12]), errm, errm_len));
     }
-    M->lo_packed = false;
     return 0;
 }
 
@@ -1184,54 +1175,32 @@ int beom_multi_profile_stop(beom_multi_handle M, double *ms, int *launches, char
 }  // extern "C"
 
 // ---- one time step of all local bands -------------------------------------------------------------
+// Boundary first (beom_step_phase): a band's main stream runs the step up to the momentum sweeps on all rows, then the
+// momentum sweep on the rows in between; its second stream, behind the first part, runs the momentum sweep on the strips
+// next to the ghost zones, packs the outermost owned rows, moves them, unpacks what the neighbours sent.  The main stream
+// looks at the second one exactly once per step — "have my ghost rows landed?" before the next step starts — and by then
+// the exchange has had the whole interior sweep to finish.  Steps that cannot be cut that way (open-boundary passes, the
+// separate u and v sweeps, option "overlap" = 0) run whole, the exchange after them.
 static int multi_one_step(beom_multi *M, int t, double tres, double dtd8, double dt_r, double rsta, int n_3d,
                           char *errm, int errm_len) {
     const int n = M->n;
     const int mk = M->mini_k;
-    std::vector<char> split(n, 0);
     if (M->shm && M->shm->failed) { m_err(errm, errm_len, "beom_multi: a neighbour's ghost rows did not arrive within %.0f s (shared-memory transport)", M->shm->timeout_s); return -35; }
-    // the companion frame's copy of rows 1..6 (state before this step); later steps pack it right after the step
-    if (M->mini && !M->lo_packed) {
-        M_HIP(hipSetDevice(M->dev[mk]));
-        if (M->free_recorded) M_HIP(hipStreamWaitEvent(M->main_s[mk], M->ev_free, 0));
-        if (beom_pack_rows(M->eng[mk], M->band[mk].gs + 1, kMiniLo, M->mini_lo)) { m_err(errm, errm_len, "beom_pack_rows failed"); return -3; }
-        M_HIP(hipEventRecord(M->ev_lo, M->main_s[mk]));
-        M->lo_packed = true;
-    }
-    // phase 1: the rows that cannot depend on the ghosts still in flight
+    // the ghost rows of the previous step have landed: before this step reads them
     for (int k = 0; k < n; ++k) {
-        if (!M->pending[k] || !M->overlap) continue;
+        if (!M->pending[k]) continue;
         M_HIP(hipSetDevice(M->dev[k]));
-        M_HIP(hipEventRecord(M->p1start[k], M->main_s[k]));       // everything of the previous step is ahead of this point
-        const int rc = beom_step_phase(M->eng[k], t, tres, dtd8, dt_r, rsta, n_3d, 1, errm, errm_len);
-        if (rc == 0) split[k] = 1;
-        else if (rc != -20) return rc;
+        M_HIP(hipStreamWaitEvent(M->main_s[k], M->landed[k], 0));
     }
-    // ghosts of the previous step have landed (mine: before I read them; with peer copies also my
-    // neighbours': before I overwrite the send buffers they copy from)
-    for (int k = 0; k < n; ++k) {
-        M_HIP(hipSetDevice(M->dev[k]));
-        // a split band's edge strips go to the band's edge stream: behind the previous step (p1start), behind the ghosts
-        hipStream_t both[2] = {M->main_s[k], (split[k] && M->edge_stream) ? M->edge_s[k] : nullptr};
-        if (both[1]) M_HIP(hipStreamWaitEvent(both[1], M->p1start[k], 0));
-        for (hipStream_t st : both) {
-            if (!st) continue;
-            if (M->pending[k]) M_HIP(hipStreamWaitEvent(st, M->landed[k], 0));
-            if (M->transport == BEOM_XCHG_PEER)
-                for (int q : {M->south_of(k), M->north_of(k)}) {
-                    const int ql = M->local_of(q);
-                    if (ql >= 0 && ql != k && M->pending[ql]) M_HIP(hipStreamWaitEvent(st, M->landed[ql], 0));
-                }
-        }
-    }
-    for (int k = 0; k < n; ++k) M->pending[k] = 0;
-    // companion frame: band 0's south ghosts (rows mm-3..mm) are fresh now -> refresh, then its step
+    // companion frame of a ring: rows 1..6 of band 0 and its south ghosts (= rows mm-3..mm) as they stand before this
+    // step, then the companion's own step on its own stream
     if (M->mini) {
         M_HIP(hipSetDevice(M->dev[mk]));
-        if (M->free_recorded) M_HIP(hipStreamWaitEvent(M->main_s[mk], M->ev_free, 0));
-        if (beom_pack_rows(M->eng[mk], 1, kGhost, M->mini_hi)) { m_err(errm, errm_len, "beom_pack_rows failed"); return -3; }
+        if (M->free_recorded) M_HIP(hipStreamWaitEvent(M->main_s[mk], M->ev_free, 0));      // (the companion has taken the copies of the step before)
+        if (beom_pack_rows(M->eng[mk], M->band[mk].gs + 1, kMiniLo, M->mini_lo) || beom_pack_rows(M->eng[mk], 1, kGhost, M->mini_hi)) {
+            m_err(errm, errm_len, "beom_pack_rows failed"); return -3;
+        }
         M_HIP(hipEventRecord(M->ev_hi, M->main_s[mk]));
-        M_HIP(hipStreamWaitEvent(M->mini_s, M->ev_lo, 0));
         M_HIP(hipStreamWaitEvent(M->mini_s, M->ev_hi, 0));
         if (beom_unpack_rows(M->mini, 1, kMiniLo, M->mini_lo) || beom_unpack_rows(M->mini, kMiniLo + 1, kGhost, M->mini_hi)) {
             m_err(errm, errm_len, "beom_unpack_rows failed"); return -3;
@@ -1240,37 +1209,47 @@ static int multi_one_step(beom_multi *M, int t, double tres, double dtd8, double
         M->free_recorded = true;
         M_RC(beom_step(M->mini, t, 1, tres, dtd8, dt_r, rsta, n_3d, errm, errm_len));
     }
-    // the rest of the step, then pack what the neighbours need = my outermost OWNED rows
+    // the step; a band's packing stream X is its second stream when the step is cut, else its main stream
+    std::vector<hipStream_t> X(n, nullptr);
     for (int k = 0; k < n; ++k) {
         const Band &s = M->band[k];
-        if (split[k] && M->edge_stream) {
-            // the strips next to the ghost zones: three small launches that would otherwise FOLLOW the interior sweeps run
-            // inside them (each waits for the interior sweep before it, beom_step_phase); the band's stream goes on after them
-            M_HIP(hipSetDevice(M->dev[k]));
-            struct Back { beom_multi *M; int k; ~Back() { (void)beom_set_stream(M->eng[k], (void *)M->main_s[k], 0); } } back{M, k};
-            (void)beom_set_stream(M->eng[k], (void *)M->edge_s[k], 0);
-            if (M->mini && k == mk) M_HIP(hipStreamWaitEvent(M->edge_s[k], M->ev_hi, 0));   // (the companion frame's copy of the ghost rows is taken first)
+        M_HIP(hipSetDevice(M->dev[k]));
+        struct Back { beom_multi *M; int k; ~Back() { (void)beom_set_stream(M->eng[k], (void *)M->main_s[k], 0); } } back{M, k};
+        int rc = M->overlap ? beom_step_phase(M->eng[k], t, tres, dtd8, dt_r, rsta, n_3d, 1, errm, errm_len) : -20;
+        if (rc == 0) {
+            M_HIP(hipEventRecord(M->p1done[k], M->main_s[k]));
+            M_HIP(hipStreamWaitEvent(M->comm_s[k], M->p1done[k], 0));
+            (void)beom_set_stream(M->eng[k], (void *)M->comm_s[k], 0);
             M_RC(beom_step_phase(M->eng[k], t, tres, dtd8, dt_r, rsta, n_3d, 2, errm, errm_len));
-            M_HIP(hipEventRecord(M->p2done[k], M->edge_s[k]));
-            M_HIP(hipStreamWaitEvent(M->main_s[k], M->p2done[k], 0));
+            (void)beom_set_stream(M->eng[k], (void *)M->main_s[k], 0);
+            M_RC(beom_step_phase(M->eng[k], t, tres, dtd8, dt_r, rsta, n_3d, 3, errm, errm_len));
+            X[k] = M->comm_s[k];
             ++M->n_split;
-        } else if (split[k]) { M_RC(beom_step_phase(M->eng[k], t, tres, dtd8, dt_r, rsta, n_3d, 2, errm, errm_len)); ++M->n_split; }
-        else { M_RC(beom_step(M->eng[k], t, 1, tres, dtd8, dt_r, rsta, n_3d, errm, errm_len)); ++M->n_plain; }
+        } else if (rc == -20) {
+            M_RC(beom_step(M->eng[k], t, 1, tres, dtd8, dt_r, rsta, n_3d, errm, errm_len));
+            // peer copies read a neighbour's send buffer from ITS stream: keep the exchange of a whole step on the second
+            // stream there; RCCL and the shared-memory transport order everything themselves: no stream hop at all
+            X[k] = M->transport == BEOM_XCHG_PEER ? M->comm_s[k] : M->main_s[k];
+            if (X[k] != M->main_s[k]) {
+                M_HIP(hipEventRecord(M->p1done[k], M->main_s[k]));
+                M_HIP(hipStreamWaitEvent(X[k], M->p1done[k], 0));
+            }
+            ++M->n_plain;
+        } else return rc;
+        // what the neighbours need = my outermost OWNED rows.  With peer copies my neighbours still read the send buffers
+        // of the step before until THEIR ghosts have landed.
+        if (M->transport == BEOM_XCHG_PEER)
+            for (int q : {M->south_of(k), M->north_of(k)}) {
+                const int ql = M->local_of(q);
+                if (ql >= 0 && ql != k && M->pending[ql]) M_HIP(hipStreamWaitEvent(X[k], M->landed[ql], 0));
+            }
+        (void)beom_set_stream(M->eng[k], (void *)X[k], 0);
         if (M->has_s(k) && beom_pack_rows(M->eng[k], s.gs + 1, kGhost, M->send_s[k])) { m_err(errm, errm_len, "beom_pack_rows failed"); return -3; }
         if (M->has_n(k) && beom_pack_rows(M->eng[k], s.gs + s.nown() - kGhost + 1, kGhost, M->send_n[k])) { m_err(errm, errm_len, "beom_pack_rows failed"); return -3; }
-        M_HIP(hipSetDevice(M->dev[k]));
-        M_HIP(hipEventRecord(M->packed[k], M->main_s[k]));
-        if (M->mini && k == mk) {                  // rows 1..6 after this step, for the companion frame's next step
-            M_HIP(hipStreamWaitEvent(M->main_s[k], M->ev_free, 0));
-            if (beom_pack_rows(M->eng[k], s.gs + 1, kMiniLo, M->mini_lo)) { m_err(errm, errm_len, "beom_pack_rows failed"); return -3; }
-            M_HIP(hipEventRecord(M->ev_lo, M->main_s[k]));
-        }
+        M_HIP(hipEventRecord(M->packed[k], X[k]));
     }
-    // exchange on the second streams; a band's own step has read its ghosts once packed[k] is reached
-    for (int k = 0; k < n; ++k) {
-        M_HIP(hipSetDevice(M->dev[k]));
-        M_HIP(hipStreamWaitEvent(M->comm_s[k], M->packed[k], 0));
-    }
+    for (int k = 0; k < n; ++k) M->pending[k] = 0;
+    // the exchange, in the packing stream's order
     if (M->transport == BEOM_XCHG_RCCL) {
         // sends in the order (south, north), receives in the order (north, south): with two bands in a ring, or
         // one, both neighbours are the same peer and RCCL matches a pair's messages in issue order
@@ -1279,10 +1258,10 @@ static int multi_one_step(beom_multi *M, int t, double tres, double dtd8, double
         for (int k = 0; k < n && !e; ++k) {
             if (hipSetDevice(M->dev[k]) != hipSuccess) { e = 1; break; }
             const int S = M->rank_of(M->south_of(k)), N = M->rank_of(M->north_of(k));
-            if (!e && M->has_s(k)) e = g_rccl.Send(M->send_s[k], M->xbytes, kNcclChar, S, M->comm[k], M->comm_s[k]);
-            if (!e && M->has_n(k)) e = g_rccl.Send(M->send_n[k], M->xbytes, kNcclChar, N, M->comm[k], M->comm_s[k]);
-            if (!e && M->has_n(k)) e = g_rccl.Recv(M->recv_n[k], M->xbytes, kNcclChar, N, M->comm[k], M->comm_s[k]);
-            if (!e && M->has_s(k)) e = g_rccl.Recv(M->recv_s[k], M->xbytes, kNcclChar, S, M->comm[k], M->comm_s[k]);
+            if (!e && M->has_s(k)) e = g_rccl.Send(M->send_s[k], M->xbytes, kNcclChar, S, M->comm[k], X[k]);
+            if (!e && M->has_n(k)) e = g_rccl.Send(M->send_n[k], M->xbytes, kNcclChar, N, M->comm[k], X[k]);
+            if (!e && M->has_n(k)) e = g_rccl.Recv(M->recv_n[k], M->xbytes, kNcclChar, N, M->comm[k], X[k]);
+            if (!e && M->has_s(k)) e = g_rccl.Recv(M->recv_s[k], M->xbytes, kNcclChar, S, M->comm[k], X[k]);
         }
         const int ge = g_rccl.GroupEnd();
         if (e || ge) { m_err(errm, errm_len, "RCCL ghost exchange failed: %s", g_rccl.GetErrorString(e ? e : ge)); return -300 - (e ? e : ge); }
@@ -1293,43 +1272,45 @@ static int multi_one_step(beom_multi *M, int t, double tres, double dtd8, double
         const uint64_t sq = ++x->seq;
         const int me = M->band[k].index;
         M_HIP(hipSetDevice(M->dev[k]));
-        if (M->has_s(k)) M_HIP(hipMemcpyAsync(x->slot(me, 0, sq), M->send_s[k], M->xbytes, hipMemcpyDeviceToHost, M->comm_s[k]));
-        if (M->has_n(k)) M_HIP(hipMemcpyAsync(x->slot(me, 1, sq), M->send_n[k], M->xbytes, hipMemcpyDeviceToHost, M->comm_s[k]));
-        M_HIP(hipLaunchHostFunc(M->comm_s[k], shm_publish, new ShmOp{x, me, sq}));
+        if (M->has_s(k)) M_HIP(hipMemcpyAsync(x->slot(me, 0, sq), M->send_s[k], M->xbytes, hipMemcpyDeviceToHost, X[k]));
+        if (M->has_n(k)) M_HIP(hipMemcpyAsync(x->slot(me, 1, sq), M->send_n[k], M->xbytes, hipMemcpyDeviceToHost, X[k]));
+        M_HIP(hipLaunchHostFunc(X[k], shm_publish, new ShmOp{x, me, sq}));
         if (M->has_n(k)) {          // what my north neighbour sent south (looped back: what I sent myself)
             const int q = M->north_of(k), dir = M->loopback ? (M->has_s(k) ? 0 : 1) : 0;
-            M_HIP(hipLaunchHostFunc(M->comm_s[k], shm_wait, new ShmOp{x, q, sq}));
-            M_HIP(hipMemcpyAsync(M->recv_n[k], x->slot(q, dir, sq), M->xbytes, hipMemcpyHostToDevice, M->comm_s[k]));
+            M_HIP(hipLaunchHostFunc(X[k], shm_wait, new ShmOp{x, q, sq}));
+            M_HIP(hipMemcpyAsync(M->recv_n[k], x->slot(q, dir, sq), M->xbytes, hipMemcpyHostToDevice, X[k]));
         }
         if (M->has_s(k)) {
             const int q = M->south_of(k), dir = M->loopback ? (M->has_n(k) ? 1 : 0) : 1;
-            M_HIP(hipLaunchHostFunc(M->comm_s[k], shm_wait, new ShmOp{x, q, sq}));
-            M_HIP(hipMemcpyAsync(M->recv_s[k], x->slot(q, dir, sq), M->xbytes, hipMemcpyHostToDevice, M->comm_s[k]));
+            M_HIP(hipLaunchHostFunc(X[k], shm_wait, new ShmOp{x, q, sq}));
+            M_HIP(hipMemcpyAsync(M->recv_s[k], x->slot(q, dir, sq), M->xbytes, hipMemcpyHostToDevice, X[k]));
         }
     }
     for (int k = 0; k < n; ++k) {
         const Band &s = M->band[k];
         M_HIP(hipSetDevice(M->dev[k]));
         struct Restore { beom_multi *M; int k; ~Restore() { (void)beom_set_stream(M->eng[k], (void *)M->main_s[k], 0); } } restore{M, k};
-        (void)beom_set_stream(M->eng[k], (void *)M->comm_s[k], 0);
+        (void)beom_set_stream(M->eng[k], (void *)X[k], 0);
         if (M->has_s(k)) {
             if (M->transport == BEOM_XCHG_PEER) {
                 const int q = M->local_of(M->south_of(k));
-                if (q != k) M_HIP(hipStreamWaitEvent(M->comm_s[k], M->packed[q], 0));
-                M_HIP(hipMemcpyPeerAsync(M->recv_s[k], M->dev[k], M->send_n[q], M->dev[q], M->xbytes, M->comm_s[k]));
+                if (q != k) M_HIP(hipStreamWaitEvent(X[k], M->packed[q], 0));
+                M_HIP(hipMemcpyPeerAsync(M->recv_s[k], M->dev[k], M->send_n[q], M->dev[q], M->xbytes, X[k]));
             }
             if (beom_unpack_rows(M->eng[k], 1, kGhost, M->recv_s[k])) { m_err(errm, errm_len, "beom_unpack_rows failed"); return -3; }
         }
         if (M->has_n(k)) {
             if (M->transport == BEOM_XCHG_PEER) {
                 const int q = M->local_of(M->north_of(k));
-                if (q != k) M_HIP(hipStreamWaitEvent(M->comm_s[k], M->packed[q], 0));
-                M_HIP(hipMemcpyPeerAsync(M->recv_n[k], M->dev[k], M->send_s[q], M->dev[q], M->xbytes, M->comm_s[k]));
+                if (q != k) M_HIP(hipStreamWaitEvent(X[k], M->packed[q], 0));
+                M_HIP(hipMemcpyPeerAsync(M->recv_n[k], M->dev[k], M->send_s[q], M->dev[q], M->xbytes, X[k]));
             }
             if (beom_unpack_rows(M->eng[k], s.gs + s.nown() + 1, kGhost, M->recv_n[k])) { m_err(errm, errm_len, "beom_unpack_rows failed"); return -3; }
         }
-        M_HIP(hipEventRecord(M->landed[k], M->comm_s[k]));
-        M->pending[k] = 1;
+        if (X[k] != M->main_s[k] || M->transport == BEOM_XCHG_PEER) {
+            M_HIP(hipEventRecord(M->landed[k], X[k]));
+            M->pending[k] = 1;
+        }
     }
     return 0;
 }

@@ -320,9 +320,11 @@ class SlabRunner:
     beom_amd.capi.Engine provides them on a GPU; tests plug in a CPU adapter over the oracle
     to exercise exactly this decomposition / exchange logic under gloo.
 
-    Overlap (GPU, `overlap=True`): the exchange of step n runs on a second HIP stream while
-    the main stream already computes the interior rows of step n+1 (beom_step_phase 1); the
-    rows next to the ghost zones follow once the ghosts have landed (phase 2)."""
+    Overlap (GPU, `overlap=True`): boundary first — the main stream runs a step up to the momentum
+    sweeps on all rows (beom_step_phase 1) and then the momentum sweep on the rows in between
+    (part 3); a second HIP stream runs that sweep on the strips next to the ghost zones (part 2),
+    packs the outermost owned rows, moves them and unpacks the neighbours' — inside the interior
+    sweep.  The main stream waits for its ghost rows once, before the next step."""
 
     def __init__(self, engine, geom: SlabGeom, nlay: int, dist=None, overlap: bool = False, mini=None):
         import torch
@@ -507,11 +509,34 @@ class SlabRunner:
         self.unpack_all()
 
     # -- overlapped form ------------------------------------------------------------------
-    def _begin_pack(self):
-        """After a step: pack the outermost owned rows on the main stream."""
-        self.pack_all()
-        self._packed = self.torch.cuda.Event()
-        self._packed.record(self.main)
+    def _begin_pack(self, stream=None):
+        """After a step (or after part 2 of a cut step, on the second stream): pack the outermost owned rows."""
+        stream = stream or self.main
+        with self.torch.cuda.stream(stream):
+            self.engine.set_stream(stream.cuda_stream)
+            self.pack_all()
+            self.engine.set_stream(self.main.cuda_stream)
+            self._packed = self.torch.cuda.Event()
+            self._packed.record(stream)
+
+    def _advance(self, t: int) -> bool:
+        """One step with its rows to send packed (event `_packed`); True if the step was cut boundary first."""
+        torch = self.torch
+        with torch.cuda.stream(self.main):
+            self._exchange_end()                         # the ghost rows of the step before have landed
+            if not self.engine.step_phase(t, 1):         # up to the momentum sweeps, all rows
+                self.engine.step(t, 1, sync=False)
+                self._begin_pack()
+                return False
+            front = torch.cuda.Event()
+            front.record(self.main)
+        self.comm.wait_event(front)
+        self.engine.set_stream(self.comm.cuda_stream)
+        self.engine.step_phase(t, 2)                     # the momentum sweep on the strips next to the ghost zones
+        self.engine.set_stream(self.main.cuda_stream)
+        self.engine.step_phase(t, 3)                     # ... on the rows in between, then the pointer rotations
+        self._begin_pack(self.comm)
+        return True
 
     def _begin_transfer(self, transfer=None):
         """Send/recv + unpack on the comm stream; `transfer` replaces the P2P (tests)."""
@@ -548,15 +573,9 @@ class SlabRunner:
                     self.engine.step(t, 1, sync=False)
                     self.exchange()
             return
-        with torch.cuda.stream(self.main):
-            for t in range(tstp_first, tstp_first + nsteps):
-                if self._pending is not None and self.engine.step_phase(t, 1):
-                    self._exchange_end()                 # ghosts of the previous step have landed
-                    self.engine.step_phase(t, 2)
-                else:
-                    self._exchange_end()
-                    self.engine.step(t, 1, sync=False)
-                self._exchange_begin()
+        for t in range(tstp_first, tstp_first + nsteps):
+            self._advance(t)
+            self._begin_transfer()
 
     def finish(self):
         """Drain the exchange in flight (before reading ghost rows or leaving the timed region)."""

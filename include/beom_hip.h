@@ -171,11 +171,17 @@ int beom_step(beom_handle h, int tstp_first, int nsteps,
 int beom_sync(beom_handle h, char *errm, int errm_len);
 
 /* Multi-GPU j-slabs (no reference counterpart — the reference is OpenMP only).
- * One time step in two parts so that the ghost-row exchange of the previous step overlaps
- * the bulk of this one: phase 1 = every sweep on the rows that cannot depend on ghost rows
- * still in flight, phase 2 = the rows next to the ghost zones + pointer rotations (call it
- * once the ghosts have been refreshed).  -20 = not available for this step (steps 1-3,
- * stress update, unfused path): use beom_step. */
+ * One time step of a band (a handle with slab_mm != 0) in three parts, "boundary first", so that the rows its neighbours
+ * wait for are finished, packed and on their way while the bulk of the momentum sweep still runs:
+ *   phase 1 = the step up to the momentum sweeps on all rows (stress, the transports of steps 1-3, update_h,
+ *             update_mont..., update_viscosity);
+ *   phase 2 = update_u/update_v (the fused sweep) on the strips next to the ghost zones: rows 1..8 and M-7..M — call it
+ *             with ANOTHER stream set (beom_set_stream) that waits for phase 1, and follow it there with
+ *             beom_pack_rows -> transport -> beom_unpack_rows;
+ *   phase 3 = the same sweep on the rows in between, on the usual stream, then the pointer rotations (call it last).
+ * All three see ghost rows that have landed; the next step may start once this step's unpack has run.
+ * -20 (from phase 1) = this step cannot be cut that way (separate u and v sweeps, open-boundary passes, rigid lid, fewer
+ * than 32 rows): use beom_step. */
 int beom_step_phase(beom_handle h, int tstp, double tres, double dtd8, double dt_r, double rsta,
                     int n_3d, int phase, char *errm, int errm_len);
 /* Rows [jlo, jlo+nrows) (local, 1-based) of hlay,u,v,h_u,h_v <-> one contiguous DEVICE buffer
@@ -195,22 +201,12 @@ int beom_unpack_rows(beom_handle h, int jlo, int nrows, const void *device_buffe
  *  "lean_d2h", "lean_visc" (default 1): the fused pair re-derives d2hx, d2hy in the momentum sweep,
  *      and drops the viscous products altogether when v_cc = v_ll = +0 and never refreshed.
  *  "fuse_uv" (default 1): update_u and update_v of a step run as ONE sweep.
- *  "fuse_muv" (default 0 — measured slower than the two fused sweeps): with both fusions above, "lean_d2h", and a viscosity refreshed every step or never
- *      after step 3: update_mont..., update_viscosity, update_u and update_v run as ONE sweep that derives
- *      mont, pvor and the viscous products in LDS (never stored); only the frame's edge tiles still go
- *      through the separate Montgomery sweep.
  *  "fuse": sets both.  0 = always five separate sweeps.
- *  "graph" (default 0): 1 = steady forward-backward steps (after the third, no tide, n_3d = 1, wind fully ramped up) are
- *      replayed from HIP graphs, each holding one full period of the pointer rotations; -1 = only for dense frames of at
- *      most 4 M cell-layers.  Measured on the soliton (2048x256) and Stommel (128x128) frames: no gain over individual
- *      launches (the sweeps of such frames are bound by their own dependent memory round trips), hence off by default.
  *  "profile_stride" (default 1): beom_profile_start brackets only the steps with tstp % stride == 0 with HIP events
  *      (an event pair between two launches costs a few microseconds of pipeline bubble: sampled, the timed region is
  *      hardly disturbed; the launch counts beom_profile_stop returns are those of the sampled steps).
  * Returns -3 for an unknown name. */
 int beom_set_option(beom_handle h, const char *name, int value);
-/* how many time steps of this handle ran from HIP graphs / as individual launches */
-int beom_graph_stats(beom_handle h, long long *graph_steps, long long *eager_steps);
 
 /* Run all launches of this handle on the caller's HIP stream (e.g. the stream a
  * ghost-row exchange is enqueued on).  hip_stream may be NULL = the default stream;
@@ -253,8 +249,8 @@ int beom_profile_steps(beom_handle h, int tstp_first, int nsteps,
  * No reference counterpart (the reference is OpenMP only).  The whole DENSE frame (ndeg = (lm+1)(mm+1))
  * is cut into bands of rows, one band per HIP device, each an ordinary slab handle with 4 ghost rows
  * per neighbour; per time step ONE exchange of hlay,u,v,h_u,h_v (beom_pack_rows -> transport ->
- * beom_unpack_rows on the band's second stream) overlapped with phase 1 of the next step; the steps of
- * one beom_multi_step call run inside the library.  Results are bit-identical to the single handle.
+ * beom_unpack_rows on the band's second stream) inside the interior rows of the step's own momentum sweep
+ * (beom_step_phase); the steps of one beom_multi_step call run inside the library.  Results are bit-identical to the single handle.
  * Frames periodic in y: the bands form a ring over rows 1..mm and row mm+1 (which nothing points to but
  * every record contains, private_mod.f95:642-668) is carried by a small companion frame next to band 0.
  *
@@ -327,9 +323,9 @@ int beom_multi_step(beom_multi_handle h, int tstp_first, int nsteps,
                     double tres, double dtd8, double dt_r, double rsta, int n_3d,
                     char *errm, int errm_len);
 int beom_multi_sync(beom_multi_handle h, char *errm, int errm_len);
-/* how many band-steps ran in two phases (exchange overlapped) and how many in one piece */
+/* how many band-steps were cut boundary first (exchange inside the momentum sweep) and how many ran in one piece */
 int beom_multi_stats(beom_multi_handle h, long long *split_band_steps, long long *plain_band_steps);
-/* "overlap" (default 1; 0 = every step waits for its ghost rows before it starts); other names go to every band */
+/* "overlap" (default 1; 0 = every step runs in one piece, the exchange after it); other names go to every band */
 int beom_multi_set_option(beom_multi_handle h, const char *name, int value);
 int beom_multi_describe(beom_multi_handle h, int *bands_total, int *bands_local, int *transport, int *ring,
                         int *rccl_version);

@@ -271,18 +271,48 @@ CASES = {
 }
 
 
+# Restarted runs (rsta = 1, private_mod.f95:238, 1299-1420, 1862-1866, 1887, 1898-1901): the case is first run from rest
+# with outputs; then the reference is built again with rsta = 1 and run in the SAME directory — it continues from the last
+# complete record (real*4 eta_, u___, v___; tres = the last entry of time.txt) with three plain forward-backward steps, no
+# wind ramp, and ctim = tres + dtd8*tstp.  The fixture holds the first run's files (pre_file_*: what the restart found in
+# odir), the FP64 state of the restarted run and the files after it.
+RESTART_CASES = {
+    "restart_island_3l_forced": (lambda: case_island(3), "private_mod.f95"),     # wind ramp (dt_r) switched off by rsta
+    "restart_tide_sponge": (lambda: (lambda pf: (pf[0].replace(dt_o="%.9f" % (5.01 * float(pf[0].dt) / 86400.0)), pf[1]))(case_tide()),
+                            "private_mod.f95"),                                   # tidal phase w_ti*ctim continues at tres
+}
+OUTPUT_FILES = ("grid.bin", "h_0.bin", "eta_.bin", "u___.bin", "v___.bin", "pvor.bin", "mont.bin", "v_cc.bin")
+
+
+def _collect_files(work, prefix, out):
+    for fn in OUTPUT_FILES:
+        if os.path.exists(os.path.join(work, fn)):
+            out[prefix + fn.replace(".", "_")] = np.fromfile(os.path.join(work, fn), dtype=np.uint8)
+    for fn in ("time.txt", "param_basin.txt"):
+        with open(os.path.join(work, fn)) as fh:
+            out[prefix + fn.replace(".", "_")] = np.array(fh.read())
+
+
 def generate(name):
     import ref_build
     import refdump
-    builder, engine = CASES[name]
+    restart = name in RESTART_CASES
+    builder, engine = (RESTART_CASES if restart else CASES)[name]
     p, files = builder()
     work = os.path.join("/tmp", "beom_golden", name)
     shutil.rmtree(work, ignore_errors=True)
     os.makedirs(work)
-    exe = ref_build.build(p, os.path.join(ROOT, "oracle", "_ref", "golden_" + name), engine)
     I.write_inputs(work, files)
+    pre = {}
+    if restart:
+        exe0 = ref_build.build(p, os.path.join(ROOT, "oracle", "_ref", "golden_" + name + "_first"), engine)
+        ref_build.run(exe0, work)
+        _collect_files(work, "pre_file_", pre)
+        p = p.replace(rsta="1.")
+    exe = ref_build.build(p, os.path.join(ROOT, "oracle", "_ref", "golden_" + name), engine)
     ref_build.run(exe, work, dump_upto=max(STEPS))
     out = {"params_json": np.array(json.dumps(p.to_json())), "engine": np.array(engine)}
+    out.update(pre)
     for k, a in files.items():
         out["in_" + k] = np.asarray(a).astype(np.float32)
     st = refdump.read_static(os.path.join(work, "oracle_static.bin"))
@@ -292,13 +322,7 @@ def generate(name):
         d = refdump.read_step(os.path.join(work, "oracle_step_%06d.bin" % t), p.nlay, p.ndeg)
         for k, a in d.items():
             out["step%d_%s" % (t, k)] = np.asarray(a)
-    for fn in ("grid.bin", "h_0.bin", "eta_.bin", "u___.bin", "v___.bin", "pvor.bin", "mont.bin", "v_cc.bin"):
-        if os.path.exists(os.path.join(work, fn)):
-            out["file_" + fn.replace(".", "_")] = np.fromfile(os.path.join(work, fn), dtype=np.uint8)
-    with open(os.path.join(work, "time.txt")) as fh:
-        out["file_time_txt"] = np.array(fh.read())
-    with open(os.path.join(work, "param_basin.txt")) as fh:
-        out["file_param_basin_txt"] = np.array(fh.read())
+    _collect_files(work, "file_", out)
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **out)
     print("%-24s lm=%d mm=%d nlay=%d ndeg=%d  %.1f KiB" % (name, p.lm, p.mm, p.nlay, p.ndeg,
@@ -306,5 +330,5 @@ def generate(name):
 
 
 if __name__ == "__main__":
-    for nm in (sys.argv[1:] or list(CASES)):
+    for nm in (sys.argv[1:] or list(CASES) + list(RESTART_CASES)):
         generate(nm)

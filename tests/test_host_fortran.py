@@ -48,6 +48,9 @@ def test_drop_in_under_unchanged_reference_main_and_shared_mod(tmp_path):
 def _run_host(g, work, ngpu=1):
     exe = build_host.build(g.p, os.path.join(work, "beom_gpu"), variant=g.variant)
     inputs.write_inputs(work, g.files)
+    for fn, data in g.pre.items():       # a restarted run (rsta = 1) continues in the directory of the run before it
+        with open(os.path.join(work, fn), "w" if isinstance(data, str) else "wb") as fh:
+            fh.write(data)
     env = dict(os.environ)
     if ngpu > 1:       # bands of rows on "several" devices: all of them the one GPU of the box
         env.update(BEOM_NGPU=str(ngpu), BEOM_MULTI_WRAP_DEVICES="1")

@@ -70,10 +70,10 @@ def test_oracle_sweeps_compose_to_step(name):
     a.step(1, 5)
     p = g.p
     for tstp in range(1, 6):
-        ctim = 0.0 + float(p.dtd8) * tstp
+        ctim = f.tres + float(p.dtd8) * tstp            # tres: the record a restarted run continues from (:1887), else 0
         first3 = tstp <= 3
         ramp = 1.0
-        c = float(p.dtd8) * (1 if first3 else tstp)
+        c = f.tres + float(p.dtd8) * (1 if first3 else tstp)
         if float(p.rsta) < 0.5 and c < float(p.dt_r):
             ramp = c / float(p.dt_r)
         rgld = float(p.rgld) > 0.5

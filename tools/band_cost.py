@@ -27,7 +27,7 @@ nlay = int(sys.argv[6]) if len(sys.argv) > 6 else 4
 whole_us = float(os.environ.get("BEOM_WHOLE_US", "0")) or None
 
 
-def timed(eng, K, reps=3):
+def timed(eng, K, reps=int(os.environ.get("BEOM_COST_REPS", "3"))):
     eng.step(1, 30)
     best = 1e30
     for r in range(reps):
@@ -52,13 +52,14 @@ f, g, orphan = slab.build_band(recipe, N, B)
 out["band_rows"] = {"owned": g.own1 - g.own0 + 1, "window": g.rows}
 
 # the band's rows as an ordinary slab handle, no exchange at all (ghost rows go stale: timing only)
-e = capi.Engine(f, **slab.engine_slab_args(g))
-out["slab_handle_no_exchange_us"] = round(timed(e, K), 1)
-e.close()
-print(json.dumps(out), flush=True)
+if not os.environ.get("BEOM_COST_SKIP_BASE"):
+    e = capi.Engine(f, **slab.engine_slab_args(g))
+    out["slab_handle_no_exchange_us"] = round(timed(e, K), 1)
+    e.close()
+    print(json.dumps(out), flush=True)
 
-for transport in ("shm", "rccl"):
-    for overlap in (1, 0):
+for transport in os.environ.get("BEOM_COST_TRANSPORTS", "shm,rccl").split(","):
+    for overlap in [int(x) for x in os.environ.get("BEOM_COST_OVERLAP", "1,0").split(",")]:
         kw = dict(shm_name="/beom_cost_%d_%s" % (os.getpid(), uuid.uuid4().hex[:8])) if transport == "shm" else dict(rccl_id=capi.rccl_unique_id())
         try:
             eng = capi.BandEngine(f, p, N, B, device=0, orphan=orphan, loopback=True, **kw)
@@ -75,6 +76,8 @@ for transport in ("shm", "rccl"):
         eng.close()
         print(json.dumps(out), flush=True)
 
+if os.environ.get("BEOM_COST_SKIP_BASE"):
+    sys.exit(0)
 # a closed frame with as many rows as the band owns
 pc, files = I.case_headline(lm, g.own1 - g.own0 + 1, nlay)
 e = capi.Engine(read_input_data(pc, files=files))
