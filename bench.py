@@ -12,8 +12,8 @@ region starts.
 
 N > 1: the SAME global grid is cut into N bands of rows (strong scaling), one process per GPU,
 every rank builds only its own rows from the recipe, and the K steps of the timed region run
-inside the library (beom_multi_step: ghost-row exchange over RCCL, overlapped with the interior
-rows of the next step).  Without a launcher (`python bench.py --gpus N`, no WORLD_SIZE in the
+inside the library (beom_multi_step: a step is cut boundary first — the edge strips of the momentum
+sweep, the packing and the ghost-row exchange over RCCL run inside the sweep's interior rows).  Without a launcher (`python bench.py --gpus N`, no WORLD_SIZE in the
 environment) this script starts its own N ranks before anything touches a GPU; a WORLD_SIZE that
 disagrees with --gpus is an error.  torch.distributed (gloo) carries only the control plane:
 the RCCL unique id, barriers, the max over ranks.
@@ -171,8 +171,9 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE %d" % (a.gpus, world))
 
     # the CPU leg first: no process of this job has touched a GPU yet when the reference binary is started
+    # (N > 1: the other ranks wait in the rendezvous meanwhile — before anything is timed)
     cpu = None
-    if rank == 0 and a.gpus == 1 and not a.no_cpu_baseline:
+    if rank == 0 and not a.no_cpu_baseline:
         cpu = cpu_baseline(a.cpu_sample)
 
     # Libraries underneath (RCCL prints a version banner at communicator creation) write to fd 1: the ONE line this
@@ -193,7 +194,7 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         # control plane only; the ghost rows travel over RCCL inside the library
-        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=900))
 
     from beom_amd import capi, inputs, slab
     from beom_amd.grid import read_input_data
@@ -277,18 +278,12 @@ def main():
                 "fields": list(slab.EXCHANGED), "bytes_per_direction_per_step": len(slab.EXCHANGED) * p.nlay * slab.GHOST * L * 8,
                 "step_loop": "inside the library (beom_multi_step)", "state_build": "global arrays, cut by the library"
                 if a.single_process else "each rank builds its own rows from the recipe"}
-        halo["per_kernel_note"] = ("a split step launches every sweep twice (interior rows, then the strips next to the ghost zones on a "
-                                   "stream of their own INSIDE the interior sweeps): roofline.per_kernel sums both, so concurrent time "
+        halo["per_kernel_note"] = ("a cut step launches the momentum sweep twice (the strips next to the ghost zones on the second stream, "
+                                   "the rows in between on the main one, side by side): roofline.per_kernel sums both, so concurrent time "
                                    "is counted twice there; `value` is wall time")
         if rccl_failed:
             halo["fallback"] = "RCCL transport unavailable (%s): ONE process drives the %d devices over peer copies" % (rccl_failed, n_gpus)
     t_setup = time.time() - t0
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     def all_min(flag: bool) -> bool:
         if world == 1:
@@ -296,6 +291,12 @@ def main():
         t = torch.tensor([1 if flag else 0])
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return bool(t.item())
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
 
     # N > 1: on THIS machine the overlapped form (split steps around the exchange in flight) must reproduce the
     # plain form (every step waits for its ghosts) bit for bit on every band
@@ -311,10 +312,32 @@ def main():
         same = all(np.array_equal(plain[k], over[k]) for k in names)
         halo["overlap_verified_bitwise_vs_plain_exchange"] = all_min(same)
         halo["band_steps_split_vs_plain"] = eng.stats()
-        if not halo["overlap_verified_bitwise_vs_plain_exchange"]:
-            eng.set_option("overlap", 0)
         del plain, over
         reset()
+        # which form is faster on THIS machine: the step cut boundary first (edge strips, packing and the exchange inside the
+        # interior rows of the momentum sweep) or the step in one piece with the exchange behind it?  Over a wire the cut form
+        # hides the transfer; over a loop-back (one rank) there is nothing to hide.  20 + 60 steps each, untimed region.
+        form_ms = {}
+        for name, flag in (("cut", 1), ("whole", 0)):
+            eng.set_option("overlap", flag)
+            eng.step(1, 20)
+            barrier()
+            tq = time.perf_counter()
+            eng.step(21, 60)
+            barrier()
+            dtq = time.perf_counter() - tq
+            if world > 1:
+                tt = torch.tensor([dtq], dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dtq = float(tt.item())
+            form_ms[name] = dtq / 60 * 1e3
+            reset()
+        use_cut = halo["overlap_verified_bitwise_vs_plain_exchange"] and form_ms["cut"] <= form_ms["whole"]
+        if os.environ.get("BEOM_BENCH_FORM") in ("cut", "whole"):
+            use_cut = os.environ["BEOM_BENCH_FORM"] == "cut" and halo["overlap_verified_bitwise_vs_plain_exchange"]
+        eng.set_option("overlap", 1 if use_cut else 0)
+        halo["step_form"] = {"chosen": "cut boundary first (exchange inside the interior rows of the momentum sweep)" if use_cut
+                             else "whole step, exchange behind it", "ms_per_step_probe": form_ms}
 
     # pre-warm: untimed stepping so that the timed region does not start on idle clocks; then the initial state again
     prewarm_steps = 0
@@ -341,11 +364,20 @@ def main():
     s0 = gpu_sensors(pci)
     # HIP events around every launch cost a few microseconds of pipeline bubble each — 1-2 % of a 3.8 ms step, ~10 % of a
     # 0.5 ms band-step at N = 8: every 4th step of the timed region is bracketed (at least five sampled steps)
-    stride = 4 if K >= 20 else (2 if K >= 10 else 1)
+    # ... and a sampled step brackets only ONE kind of sweep, by turns, so that no bracketed launch starts in the bubble of the
+    # bracket before it (round 2: the per-kernel times summed to more than the wall time per step)
+    stride = 2 if K >= 12 else 1
+    rotate = K >= 12
     if os.environ.get("BEOM_BENCH_STRIDE") in ("1", "2", "4"):       # (A/B of the sampling itself)
         stride = int(os.environ["BEOM_BENCH_STRIDE"])
+    if os.environ.get("BEOM_BENCH_ROTATE") in ("0", "1"):
+        rotate = os.environ["BEOM_BENCH_ROTATE"] == "1"
     eng.set_option("profile_stride", stride)
-    sampled = sum(1 for t in range(W + 1, W + K + 1) if t % stride == 0)
+    eng.set_option("profile_rotate", int(rotate))
+    KIND = {0: 0, 1: 1, 2: 1, 5: 1, 3: 2, 4: 2, 6: 2, 7: 2}          # sweep class -> what a rotating step brackets (StepTimer::kind)
+    sampled_steps = [t for t in range(W + 1, W + K + 1) if t % stride == 0]
+    sampled = len(sampled_steps)
+    steps_of_kind = [sum(1 for t in sampled_steps if (not rotate) or (t // stride) % 3 == k) for k in range(3)]
     t1 = time.perf_counter()
     ms, nl = eng.profile_steps(W + 1, K)       # K steps in ONE library call, HIP events around the kernels of the sampled steps, then a sync
     barrier()
@@ -361,14 +393,16 @@ def main():
     value = units_per_step * K / elapsed
     # dominant kernel = the longest-running sweep of this run
     # a split step launches each sweep twice (interior + edge rows): account per STEP
-    per_launch_ms = [ms[i] / sampled if nl[i] else 0.0 for i in range(NCLS)]
+    per_launch_ms = [ms[i] / max(steps_of_kind[KIND[i]], 1) if nl[i] else 0.0 for i in range(NCLS)]
     dom = max(range(NCLS), key=lambda i: ms[i])
     units_per_launch = units_per_step / n_gpus           # one launch covers one band, all layers
     ach = B_ALG_KERNEL[KERNEL_ORDER[dom]] * units_per_launch / (per_launch_ms[dom] * 1e-3) / 1e9
     roof = {"bound": "hbm", "kernel": KERNEL_ORDER[dom], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": ach / HBM_PEAK_GBS, "traffic": None, "traffic_source": None, "measured_GBs": None, "measured_frac": None,
-            "avg_launch_ms": per_launch_ms[dom], "events": "HIP events around the kernels of every %s step of the timed region "
-            "(%d of %d steps)" % ({1: "", 2: "2nd", 4: "4th"}[stride], sampled, K),
+            "avg_launch_ms": per_launch_ms[dom], "events": "HIP events inside the timed region: every %s step brackets %s "
+            "(%d of %d steps sampled; %s)" % ({1: "", 2: "2nd", 4: "4th"}[stride], "ONE kind of sweep, by turns" if rotate else "its sweeps",
+                                              sampled, K, "steps per kind h / mont+visc / u+v: %s" % steps_of_kind),
+            "sum_of_kernel_ms_per_step": sum(per_launch_ms),
             "alg_bytes_per_launch": B_ALG_KERNEL[KERNEL_ORDER[dom]] * units_per_launch,
             "per_kernel": {KERNEL_ORDER[i]: {"avg_ms": per_launch_ms[i], "launches": nl[i],
                                              "alg_GBs": (B_ALG_KERNEL[KERNEL_ORDER[i]] * units_per_launch
@@ -394,6 +428,20 @@ def main():
         except Exception:
             pass
 
+    # the state after the timed region: finite, and a checksum of hlay, u, v (sum of |x| per field, over the owned rows of all ranks)
+    after = eng.download(("hlay", "u", "v"))
+    if banded and not a.single_process:
+        la, lb = geom.local_rows(geom.own0, geom.own1)
+        after = {k: v[:, la:lb] for k, v in after.items()}
+    finite = all(bool(np.isfinite(v).all()) for v in after.values())
+    sums = [float(np.abs(after[k]).sum()) for k in ("hlay", "u", "v")]
+    if world > 1:
+        tt = torch.tensor(sums + [1.0 if finite else 0.0], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        sums, finite = [float(x) for x in tt[:3]], float(tt[3]) == float(world)
+    state_check = {"finite": finite, "sum_abs": dict(zip(("hlay", "u", "v"), sums)), "after_steps": W + K}
+    del after
+
     out = {
         "metric": "cell-layer updates/s", "value": value, "unit": "cell-layer updates/s",
         "n_gpus": n_gpus, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
@@ -405,7 +453,7 @@ def main():
                    "dense_fast_path": bool(dense), "setup_s": round(t_setup, 1),
                    "prewarm": {"seconds": a.prewarm_s, "steps": prewarm_steps,
                                "note": "untimed; the initial state is uploaded again before the W warm-up steps"},
-                   "gpu_at_start": s0, "gpu_at_end": s1},
+                   "gpu_at_start": s0, "gpu_at_end": s1, "state_after_timed_region": state_check},
         "roofline": roof,
     }
     if halo:

@@ -150,6 +150,8 @@ def load(path: Optional[str] = None) -> C.CDLL:
     lib.beom_step_phase.argtypes = [H, ci, cd, cd, cd, cd, ci, ci, cp, ci]
     lib.beom_pack_rows.argtypes = [H, ci, ci, C.c_void_p]
     lib.beom_unpack_rows.argtypes = [H, ci, ci, C.c_void_p]
+    lib.beom_pack_rows2.argtypes = [H, ci, ci, C.c_void_p, ci, C.c_void_p]
+    lib.beom_unpack_rows2.argtypes = [H, ci, ci, C.c_void_p, ci, C.c_void_p]
     lib.beom_profile_start.argtypes = [H]
     lib.beom_profile_stop.argtypes = [H, dpp, C.POINTER(ci), cp, ci]
     lib.beom_update_h.argtypes = [H, cd, cd, cd]
@@ -159,6 +161,8 @@ def load(path: Optional[str] = None) -> C.CDLL:
     lib.beom_update_v.argtypes = [H, ci, cd, cd, cd]
     lib.beom_rebuild_fluxes.argtypes = [H]
     lib.beom_distribute_stress.argtypes = [H]
+    lib.beom_info.argtypes = [H, cp]
+    lib.beom_info.restype = ci
     lib.beom_device_field.argtypes = [H, cp, C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
                                       C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.beom_is_dense.argtypes = [H]
@@ -203,7 +207,7 @@ def load(path: Optional[str] = None) -> C.CDLL:
                  "beom_update_u", "beom_update_v", "beom_rebuild_fluxes", "beom_distribute_stress",
                  "beom_device_field", "beom_is_dense", "beom_profile_steps", "beom_set_stream",
                  "beom_profile_start", "beom_profile_stop", "beom_set_option", "beom_step_phase",
-                 "beom_pack_rows", "beom_unpack_rows", "beom_download_outputs", "beom_set_open_boundaries"):
+                 "beom_pack_rows", "beom_unpack_rows", "beom_pack_rows2", "beom_unpack_rows2", "beom_download_outputs", "beom_set_open_boundaries"):
         getattr(lib, name).restype = ci
     if lib.beom_abi_version() != BEOM_ABI_VERSION:
         raise RuntimeError("ABI mismatch")
@@ -211,13 +215,13 @@ def load(path: Optional[str] = None) -> C.CDLL:
     return lib
 
 
-EXPORTS = ("beom_abi_version", "beom_device_count", "beom_device_pci_bus_id", "beom_download_diag", "beom_create", "beom_destroy", "beom_set_rigid_lid", "beom_download_pressure",
+EXPORTS = ("beom_abi_version", "beom_device_count", "beom_device_pci_bus_id", "beom_info", "beom_download_diag", "beom_create", "beom_destroy", "beom_set_rigid_lid", "beom_download_pressure",
            "beom_upload_state", "beom_download_state", "beom_download_scratch", "beom_step",
            "beom_sync", "beom_update_h", "beom_update_mont_rvor_pvor_dive_kine",
            "beom_update_viscosity", "beom_update_u", "beom_update_v", "beom_rebuild_fluxes",
            "beom_distribute_stress", "beom_device_field", "beom_is_dense", "beom_profile_steps",
            "beom_set_stream", "beom_profile_start", "beom_profile_stop", "beom_set_option",
-           "beom_step_phase", "beom_pack_rows", "beom_unpack_rows", "beom_download_outputs",
+           "beom_step_phase", "beom_pack_rows", "beom_unpack_rows", "beom_pack_rows2", "beom_unpack_rows2", "beom_download_outputs",
            "beom_set_open_boundaries",
            "beom_multi_create", "beom_multi_destroy", "beom_multi_count", "beom_multi_band",
            "beom_multi_upload_state", "beom_multi_download_state", "beom_multi_step", "beom_multi_sync",
@@ -373,6 +377,14 @@ class Engine:
         nl = (C.c_int * 8)()
         self._check(self.lib.beom_profile_stop(self.h, ms, nl, self._err, ERRLEN))
         return list(ms)[:8], list(nl)[:8]
+
+    def info(self, what: str) -> int:
+        """beom_info: "stress_folded" (the last step formed its stress inside the momentum sweep: tt3d, tb3d, tu3d are
+        then not kept current), "tile_rows"."""
+        v = self.lib.beom_info(self.h, what.encode())
+        if v < 0:
+            raise BeomError("beom_info(%s) = %d" % (what, v))
+        return v
 
     def field_tensors(self, names=("hlay", "u", "v", "h_u", "h_v")):
         """Zero-copy torch views [nlay, layer stride] of the device-resident prognostic fields.  Handles on the
@@ -543,6 +555,13 @@ class MultiEngine:
     def set_option(self, name: str, value: int):
         """"overlap": split steps around the exchange in flight; other names go to every band."""
         self._check(self.lib.beom_multi_set_option(self.h, name.encode(), int(value)))
+
+    def info(self, what: str) -> int:
+        """beom_info of band 0's handle (all bands of a frame run the same launches)."""
+        v = self.lib.beom_info(self.band_engine_handle(0), what.encode())
+        if v < 0:
+            raise BeomError("beom_info(%s) = %d" % (what, v))
+        return v
 
     def band_engine_handle(self, k: int) -> C.c_void_p:
         h = C.c_void_p()

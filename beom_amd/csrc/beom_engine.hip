@@ -54,8 +54,19 @@ struct StepTimer {        // optional HIP-event bracket around each kernel class
     std::vector<hipEvent_t> ev; std::vector<int> cls;
     hipStream_t st;
     int stride = 1;       // only the steps with tstp % stride == 0 are bracketed (an event pair costs a few us of pipeline bubble)
-    void begin(int c) { hipEvent_t a; (void)hipEventCreate(&a); (void)hipEventRecord(a, st); ev.push_back(a); cls.push_back(c); }
-    void end() { hipEvent_t b; (void)hipEventCreate(&b); (void)hipEventRecord(b, st); ev.push_back(b); }
+    // rotate: a sampled step brackets ONE kind of sweep only — update_h | Montgomery, viscosity | momentum — by turns
+    // ((tstp / stride) % 3), so no bracketed launch has another bracket's bubble in front of it
+    bool rotate = false;
+    int slot = -1;        // the kind this step brackets (-1: all)
+    bool open = false;
+    static int kind(int c) { return c == 0 ? 0 : (c == 1 || c == 2 || c == 5) ? 1 : 2; }
+    void step(int tstp) { slot = rotate ? (tstp / stride) % 3 : -1; }
+    void begin(int c) {
+        open = slot < 0 || kind(c) == slot;
+        if (!open) return;
+        hipEvent_t a; (void)hipEventCreate(&a); (void)hipEventRecord(a, st); ev.push_back(a); cls.push_back(c);
+    }
+    void end() { if (!open) return; hipEvent_t b; (void)hipEventCreate(&b); (void)hipEventRecord(b, st); ev.push_back(b); open = false; }
 };
 
 struct beom_engine {
@@ -77,7 +88,9 @@ struct beom_engine {
     // distribute_stress inside the fused momentum sweep (option "fold_stress", default on): possible when the fractions are
     // constants (ocrp = 0) and nothing the sweep would have to read was uploaded into an array the engine does not refresh
     bool fold_stress = true, fold_static_ok = false;
+    bool fold_leith = true;            // option "fold_leith": the Leith products of deep tiles are formed inside the fused u+v sweep
     bool up_tt = false, up_tb = false, up_tu = false;   // a non-zero tt3d / tb3d / tu3d has been uploaded
+    bool last_folded = false;          // the last step formed its stress inside the momentum sweep (beom_info "stress_folded")
     float *h0r4_dev = nullptr, *out4[3] = {nullptr, nullptr, nullptr};   // device-side output staging
     float *diag4[3] = {nullptr, nullptr, nullptr};
     double *scan_dev = nullptr;
@@ -94,6 +107,7 @@ struct beom_engine {
     std::vector<int32_t> subc_host, neig_host, dev_index;
     bool lid = false, lid_ready = false;
     int profile_stride = 1;            // option "profile_stride"
+    bool profile_rotate = false;       // option "profile_rotate"
     bool split_prod = false;           // split steps: part 1's Montgomery sweep left the viscous products for parts 2 and 3
     bool tile4 = false;                // the tiled sweeps run the 64 x 4 geometry (frames of one or two rounds of workgroups)
     char last_err[512] = {0};
@@ -429,7 +443,8 @@ int beom_create(const beom_params *prm, int device, const int32_t *neig, const i
     E->top = prm->tdrg > 1.e-7;                                                                                  // :1991
     d.has_wind = E->wind; d.has_bot = E->bot; d.has_top = E->top;
     d.has_stress = E->wind || E->bot || E->top;
-    d.stress_fold = 0;
+    d.stress_fold = 0; d.prod_in_uv = 0;
+    E->fold_leith = getenv("BEOM_NO_FOLD_LEITH") == nullptr;
     d.rho_top = prm->rhon[0]; d.rho_bot = prm->rhon[nl - 1];
     {
         bool neg0 = false;                         // a body force of exactly -0 would make the sign of a skipped +-0 visible
@@ -786,6 +801,7 @@ static bool launch_mont_visc(beom_engine *E, bool uv_fused_follows, bool leith, 
     E->d.keep_visc = keep_visc;
     E->d.zero_visc = !leith && uv_fused_follows && E->lean_visc && E->visc_all_zero && E->P.dvis == 0.0 && E->P.bvis == 0.0 &&
                      !E->d.keep_diag;
+    E->d.prod_in_uv = leith && uv_fused_follows && E->fold_leith && !keep_visc && !E->d.keep_diag;
     return E->tile4 ? raw_mont_visc_t4(E, leith) : raw_mont_visc_t8(E, leith);
 }
 // fused U+V sweep (dense frames): first_x = update_u first (even tstp)
@@ -886,8 +902,9 @@ static bool stress_folds(const beom_engine *E, const StepScalars &s) {
 
 static void one_step(beom_engine *E, int tstp, const StepScalars &s) {
     StepTimer *T = (E->timer && tstp % E->timer->stride == 0) ? E->timer : nullptr;
-    if (T) T->st = E->stream;
+    if (T) { T->st = E->stream; T->step(tstp); }
     E->d.stress_fold = stress_folds(E, s) ? 1 : 0;
+    E->last_folded = E->d.stress_fold != 0;
     if (s.stress && !E->d.stress_fold) launch_stress(E);
     if (E->lid) launch_lid_fluxes(E, s.first3);
     else if (s.first3) launch_rebuild(E);                          // :2166-2177
@@ -931,6 +948,18 @@ static void one_step(beom_engine *E, int tstp, const StepScalars &s) {
     E->d.stress_fold = 0;
 }
 
+// rows [jlo, jlo+nrows) of hlay,u,v,h_u,h_v  ->  dbuf (device memory, 5*nlay*nrows*(lm+1) doubles); the *2 forms move a second
+// group of as many rows to / from a second buffer in the same launch
+template <bool PACK>
+static int rows_copy(beom_handle E, int jlo, int nrows, void *dbuf, int jlo2, void *dbuf2) {
+    if (!E || !dbuf || jlo < 1 || nrows < 1 || jlo + nrows - 1 > E->d.M) return -3;
+    if (dbuf2 && (jlo2 < 1 || jlo2 + nrows - 1 > E->d.M)) return -3;
+    if (hipSetDevice(E->device) != hipSuccess) return -9;
+    const long long total = 5ll * E->d.nlay * nrows * E->d.L;
+    hipLaunchKernelGGL((k_rows_copy<PACK>), dim3((unsigned)((total + BEOM_BLOCK - 1) / BEOM_BLOCK), dbuf2 ? 2u : 1u), dim3(BEOM_BLOCK),
+                       0, E->stream, E->d, jlo, nrows, (double *)dbuf, jlo2, (double *)dbuf2);
+    return hipGetLastError() == hipSuccess ? 0 : -10;
+}
 extern "C" {
 
 int beom_step(beom_handle E, int tstp_first, int nsteps, double tres, double dtd8, double dt_r,
@@ -952,6 +981,7 @@ int beom_profile_start(beom_handle E) {
     E->timer = new StepTimer();
     E->timer->st = E->stream;
     E->timer->stride = E->profile_stride;
+    E->timer->rotate = E->profile_rotate;
     return 0;
 }
 
@@ -1016,8 +1046,9 @@ int beom_step_phase(beom_handle E, int tstp, double tres, double dtd8, double dt
     const int M = d.M;
     const bool u_first = tstp % 2 == 0;
     StepTimer *T = (E->timer && tstp % E->timer->stride == 0) ? E->timer : nullptr;
-    if (T) T->st = E->stream;
+    if (T) { T->st = E->stream; T->step(tstp); }
     E->d.stress_fold = stress_folds(E, s) ? 1 : 0;
+    E->last_folded = E->d.stress_fold != 0;
     if (phase == 1) {                                                  // one_step up to the momentum sweeps
         if (s.stress && !E->d.stress_fold) launch_stress(E);
         if (s.first3) launch_rebuild(E);                               // :2166-2177
@@ -1053,22 +1084,13 @@ int beom_step_phase(beom_handle E, int tstp, double tres, double dtd8, double dt
     return 0;
 }
 
-// rows [jlo, jlo+nrows) of hlay,u,v,h_u,h_v  ->  dbuf (device memory, 5*nlay*nrows*(lm+1) doubles)
-int beom_pack_rows(beom_handle E, int jlo, int nrows, void *dbuf) {
-    if (!E || !dbuf || jlo < 1 || nrows < 1 || jlo + nrows - 1 > E->d.M) return -3;
-    if (hipSetDevice(E->device) != hipSuccess) return -9;
-    const long long total = 5ll * E->d.nlay * nrows * E->d.L;
-    hipLaunchKernelGGL((k_rows_copy<true>), dim3((unsigned)((total + BEOM_BLOCK - 1) / BEOM_BLOCK)), dim3(BEOM_BLOCK),
-                       0, E->stream, E->d, jlo, nrows, (double *)dbuf);
-    return hipGetLastError() == hipSuccess ? 0 : -10;
+int beom_pack_rows(beom_handle E, int jlo, int nrows, void *dbuf) { return rows_copy<true>(E, jlo, nrows, dbuf, 0, nullptr); }
+int beom_unpack_rows(beom_handle E, int jlo, int nrows, const void *dbuf) { return rows_copy<false>(E, jlo, nrows, const_cast<void *>(dbuf), 0, nullptr); }
+int beom_pack_rows2(beom_handle E, int nrows, int jlo_a, void *dbuf_a, int jlo_b, void *dbuf_b) {
+    return rows_copy<true>(E, jlo_a, nrows, dbuf_a, jlo_b, dbuf_b);
 }
-int beom_unpack_rows(beom_handle E, int jlo, int nrows, const void *dbuf) {
-    if (!E || !dbuf || jlo < 1 || nrows < 1 || jlo + nrows - 1 > E->d.M) return -3;
-    if (hipSetDevice(E->device) != hipSuccess) return -9;
-    const long long total = 5ll * E->d.nlay * nrows * E->d.L;
-    hipLaunchKernelGGL((k_rows_copy<false>), dim3((unsigned)((total + BEOM_BLOCK - 1) / BEOM_BLOCK)), dim3(BEOM_BLOCK),
-                       0, E->stream, E->d, jlo, nrows, (double *)dbuf);
-    return hipGetLastError() == hipSuccess ? 0 : -10;
+int beom_unpack_rows2(beom_handle E, int nrows, int jlo_a, const void *dbuf_a, int jlo_b, const void *dbuf_b) {
+    return rows_copy<false>(E, jlo_a, nrows, const_cast<void *>(dbuf_a), jlo_b, const_cast<void *>(dbuf_b));
 }
 
 // Output preparation on the device: replaces the array work of write_array for
@@ -1201,6 +1223,13 @@ int beom_set_open_boundaries(beom_handle E, int nseg, const int32_t *segm, char 
     return 0;
 }
 
+int beom_info(beom_handle E, const char *what) {
+    if (!E || !what) return -1;
+    if (!strcmp(what, "stress_folded")) return E->last_folded ? 1 : 0;
+    if (!strcmp(what, "tile_rows")) return E->dense ? (E->tile4 ? 4 : 8) : 0;
+    return -3;
+}
+
 int beom_set_option(beom_handle E, const char *name, int value) {
     if (!E || !name) return -1;
     if (!strcmp(name, "fuse")) { E->fuse = value != 0; E->fuse_uv = value != 0; }
@@ -1208,7 +1237,9 @@ int beom_set_option(beom_handle E, const char *name, int value) {
     else if (!strcmp(name, "fuse_uv")) E->fuse_uv = value != 0 && !E->lid;
     else if (!strcmp(name, "keep_diag")) E->d.keep_diag = value != 0;
     else if (!strcmp(name, "fold_stress")) E->fold_stress = value != 0;
+    else if (!strcmp(name, "fold_leith")) E->fold_leith = value != 0;
     else if (!strcmp(name, "profile_stride")) E->profile_stride = value > 0 ? value : 1;
+    else if (!strcmp(name, "profile_rotate")) E->profile_rotate = value != 0;
     else if (!strcmp(name, "lean_d2h")) E->lean_d2h = value != 0;
     else if (!strcmp(name, "lean_visc")) E->lean_visc = value != 0;
     else return -3;

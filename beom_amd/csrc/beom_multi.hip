@@ -507,7 +507,13 @@ int create_band_land(beom_multi *M, int k, const int32_t *neig, const int32_t *s
 int finish_band(beom_multi *M, int k, char *errm, int errm_len) {
     M_HIP(hipSetDevice(M->dev[k]));
     M_HIP(hipStreamCreateWithFlags(&M->main_s[k], hipStreamNonBlocking));
-    M_HIP(hipStreamCreateWithFlags(&M->comm_s[k], hipStreamNonBlocking));
+    {   // the second stream at the highest priority the device offers: its kernels (the edge strips of the momentum sweep, the
+        // packing, RCCL's send/recv) are few workgroups that must get through while the interior sweep fills the chip
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
+            M_HIP(hipStreamCreateWithPriority(&M->comm_s[k], hipStreamNonBlocking, greatest));
+        else { (void)hipGetLastError(); M_HIP(hipStreamCreateWithFlags(&M->comm_s[k], hipStreamNonBlocking)); }
+    }
     M_HIP(hipEventCreateWithFlags(&M->packed[k], hipEventDisableTiming));
     M_HIP(hipEventCreateWithFlags(&M->landed[k], hipEventDisableTiming));
     M_HIP(hipEventCreateWithFlags(&M->p1done[k], hipEventDisableTiming));
@@ -1244,8 +1250,12 @@ static int multi_one_step(beom_multi *M, int t, double tres, double dtd8, double
                 if (ql >= 0 && ql != k && M->pending[ql]) M_HIP(hipStreamWaitEvent(X[k], M->landed[ql], 0));
             }
         (void)beom_set_stream(M->eng[k], (void *)X[k], 0);
-        if (M->has_s(k) && beom_pack_rows(M->eng[k], s.gs + 1, kGhost, M->send_s[k])) { m_err(errm, errm_len, "beom_pack_rows failed"); return -3; }
-        if (M->has_n(k) && beom_pack_rows(M->eng[k], s.gs + s.nown() - kGhost + 1, kGhost, M->send_n[k])) { m_err(errm, errm_len, "beom_pack_rows failed"); return -3; }
+        if (M->has_s(k) && M->has_n(k)) {
+            if (beom_pack_rows2(M->eng[k], kGhost, s.gs + 1, M->send_s[k], s.gs + s.nown() - kGhost + 1, M->send_n[k])) { m_err(errm, errm_len, "beom_pack_rows2 failed"); return -3; }
+        } else {
+            if (M->has_s(k) && beom_pack_rows(M->eng[k], s.gs + 1, kGhost, M->send_s[k])) { m_err(errm, errm_len, "beom_pack_rows failed"); return -3; }
+            if (M->has_n(k) && beom_pack_rows(M->eng[k], s.gs + s.nown() - kGhost + 1, kGhost, M->send_n[k])) { m_err(errm, errm_len, "beom_pack_rows failed"); return -3; }
+        }
         M_HIP(hipEventRecord(M->packed[k], X[k]));
     }
     for (int k = 0; k < n; ++k) M->pending[k] = 0;
@@ -1297,7 +1307,7 @@ static int multi_one_step(beom_multi *M, int t, double tres, double dtd8, double
                 if (q != k) M_HIP(hipStreamWaitEvent(X[k], M->packed[q], 0));
                 M_HIP(hipMemcpyPeerAsync(M->recv_s[k], M->dev[k], M->send_n[q], M->dev[q], M->xbytes, X[k]));
             }
-            if (beom_unpack_rows(M->eng[k], 1, kGhost, M->recv_s[k])) { m_err(errm, errm_len, "beom_unpack_rows failed"); return -3; }
+            if (!M->has_n(k) && beom_unpack_rows(M->eng[k], 1, kGhost, M->recv_s[k])) { m_err(errm, errm_len, "beom_unpack_rows failed"); return -3; }
         }
         if (M->has_n(k)) {
             if (M->transport == BEOM_XCHG_PEER) {
@@ -1305,7 +1315,10 @@ static int multi_one_step(beom_multi *M, int t, double tres, double dtd8, double
                 if (q != k) M_HIP(hipStreamWaitEvent(X[k], M->packed[q], 0));
                 M_HIP(hipMemcpyPeerAsync(M->recv_n[k], M->dev[k], M->send_s[q], M->dev[q], M->xbytes, X[k]));
             }
-            if (beom_unpack_rows(M->eng[k], s.gs + s.nown() + 1, kGhost, M->recv_n[k])) { m_err(errm, errm_len, "beom_unpack_rows failed"); return -3; }
+            if (!M->has_s(k) && beom_unpack_rows(M->eng[k], s.gs + s.nown() + 1, kGhost, M->recv_n[k])) { m_err(errm, errm_len, "beom_unpack_rows failed"); return -3; }
+        }
+        if (M->has_s(k) && M->has_n(k) && beom_unpack_rows2(M->eng[k], kGhost, 1, M->recv_s[k], s.gs + s.nown() + 1, M->recv_n[k])) {
+            m_err(errm, errm_len, "beom_unpack_rows2 failed"); return -3;       // both sides in one launch, behind both transfers
         }
         if (X[k] != M->main_s[k] || M->transport == BEOM_XCHG_PEER) {
             M_HIP(hipEventRecord(M->landed[k], X[k]));

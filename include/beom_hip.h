@@ -189,6 +189,9 @@ int beom_step_phase(beom_handle h, int tstp, double tres, double dtd8, double dt
  * handle's stream. */
 int beom_pack_rows(beom_handle h, int jlo, int nrows, void *device_buffer);
 int beom_unpack_rows(beom_handle h, int jlo, int nrows, const void *device_buffer);
+/* two groups of nrows rows (a band's south and north side) <-> two buffers in ONE launch */
+int beom_pack_rows2(beom_handle h, int nrows, int jlo_a, void *buffer_a, int jlo_b, void *buffer_b);
+int beom_unpack_rows2(beom_handle h, int nrows, int jlo_a, const void *buffer_a, int jlo_b, const void *buffer_b);
 
 /* Options (dense frames only; results are bit-identical either way):
  *  "fuse_mont_visc" (default 1): with the Leith viscosity refreshed every step (dvis > 1e-3,
@@ -205,8 +208,18 @@ int beom_unpack_rows(beom_handle h, int jlo, int nrows, const void *device_buffe
  *  "profile_stride" (default 1): beom_profile_start brackets only the steps with tstp % stride == 0 with HIP events
  *      (an event pair between two launches costs a few microseconds of pipeline bubble: sampled, the timed region is
  *      hardly disturbed; the launch counts beom_profile_stop returns are those of the sampled steps).
+ *  "profile_rotate" (default 0): a sampled step brackets only ONE kind of sweep — update_h | update_mont, update_viscosity |
+ *      update_u, update_v — by turns ((tstp / stride) % 3 = 0 | 1 | 2), so that no bracketed launch starts behind another
+ *      bracket's bubble; the launch counts are then those of the steps that bracketed that kind.
+ *  "fold_stress" (default 1): with constant layer fractions (ocrp = 0) and a stress refresh on every step (n_3d = 1), steps
+ *      after the third form distribute_stress (private_mod.f95:1921-2149) inside the fused update_u/update_v sweep: no
+ *      launch of its own, tt3d/tb3d/tu3d neither written nor read (they keep their values of step 1 unless "keep_diag" = 1).
  * Returns -3 for an unknown name. */
 int beom_set_option(beom_handle h, const char *name, int value);
+/* Introspection (>= 0, or -3 for an unknown name): "stress_folded" = the last step formed its stress inside the momentum
+ * sweep (1) or through distribute_stress' own launch and the three arrays (0); "tile_rows" = rows of a tile of the tiled
+ * sweeps (8 | 4; 0 on the table path). */
+int beom_info(beom_handle h, const char *what);
 
 /* Run all launches of this handle on the caller's HIP stream (e.g. the stream a
  * ghost-row exchange is enqueued on).  hip_stream may be NULL = the default stream;

@@ -39,6 +39,13 @@ MODES = {          # name: (dense_hint, fuse_mont_visc, fuse_uv, keep_diag)
 PROGNOSTIC = ("hlay", "u", "v", "h_u", "h_v", "rs_h", "dmdx", "dmdy", "tt3d", "tb3d", "tu3d")
 
 
+def _live(e, keys):
+    """`keys` without the stress arrays when the engine forms distribute_stress inside its momentum sweep (option
+    "fold_stress": constant layer fractions, a refresh on every step): tt3d, tb3d, tu3d are then neither written nor read —
+    the next step recomputes what they would hold — and keep their values of step 1."""
+    return [k for k in keys if not (k in ("tt3d", "tb3d", "tu3d") and e.info("stress_folded"))]
+
+
 def _engine(f, variant=0, mode="dense_fused", **kw):
     dh, fmv, fuv, keep = MODES[mode]
     e = capi.Engine(f, variant=variant, dense_hint=dh, **kw)
@@ -75,7 +82,7 @@ def test_step_matches_reference_golden(name, mode):
         e.step(t + 1, tgt - t)
         t = tgt
         st = e.download()
-        for k in (PROGNOSTIC if lossy else STATE):
+        for k in _live(e, PROGNOSTIC if lossy else STATE):
             _check(st[k], g.step(tgt, k), exact, (name, tgt, k))
         if exact:                                  # prognostic fields and the histories the next steps read: even the sign of zero
             for k in ("hlay", "u", "v", "h_u", "h_v", "rs_h", "dmdx", "dmdy"):
@@ -155,7 +162,7 @@ def test_long_run_matches_oracle():
     e.step(1, 200)
     o.step(1, 200)
     st = e.download()
-    for k in STATE:
+    for k in _live(e, STATE):
         assert same(st[k], o.state()[k]), k
     assert np.isfinite(st["hlay"]).all()
     e.close()
@@ -195,7 +202,7 @@ def test_land_frames_on_the_rectangle_match_oracle_and_table_path(case):
     for x_ in (emb, tab, o):
         x_.step(1, 13)
     a, b = emb.download(), tab.download()
-    for k in PROGNOSTIC:
+    for k in _live(emb, PROGNOSTIC):
         assert same(a[k], o.state()[k]), (case, k, "embedded vs oracle", maxrel(a[k], o.state()[k]))
         assert same(a[k], b[k]), (case, k, "embedded vs table path")
     for k in ("hlay", "u", "v", "h_u", "h_v"):
@@ -382,13 +389,116 @@ def test_dense_interior_waves_match_oracle_and_gather(case):
     for m, e in engines.items():
         lossy = m in ("dense_fused", "dense_fuse_mv_only") and _fuses(p)
         st = e.download()
-        for k in (PROGNOSTIC if lossy else STATE):
+        for k in _live(e, PROGNOSTIC if lossy else STATE):
             assert same(st[k], o.state()[k]), (case, m, k, maxrel(st[k], o.state()[k]))
         sc = e.download_scratch()
         keys = SCRATCH if not lossy else (("mont", "pvor") if m == "dense_fused" else ("mont", "pvor", "d2hx", "d2hy"))
         for k in keys:
             assert same(sc[k], ref_sc[k]), (case, m, k)
         e.close()
+
+
+@pytest.mark.parametrize("tile_rows", [4, 8])
+@pytest.mark.parametrize("case", ["closed_3l", "jet_xyper_2l", "sill_leith_3l"])
+def test_leith_products_formed_in_momentum_sweep(case, tile_rows):
+    """Option "fold_leith" (default on): with the Leith viscosity refreshed on every step, the interior workgroups of the
+    fused u+v sweep form v_cc*dive and v_ll*rvor themselves from the u, v they stage (k_uv_fused<.., LF>) and k_mont_visc
+    neither evaluates Leith nor stores the two arrays for deep tiles.  Both tile geometries, against the oracle and against
+    the same engine with the fold off, bit for bit with the sign of zero."""
+    import os
+    from beom_amd import inputs as I
+    from beom_amd.grid import read_input_data
+    if case == "closed_3l":
+        p, files = I.case_headline(330, 75, 3)
+    elif case == "jet_xyper_2l":
+        p, files = I.case_unstable_jet(lm=331, mm=151, nlay=2, dt_s=1.5)
+    else:
+        p, files = I.case_sill_exchange3d(lm=330, mm=141, nlay=3, dt_s=0.01, npts=5, sill_halfwidth=20.0)
+    f = read_input_data(p, files=files)
+    old = os.environ.get("BEOM_TILE4")
+    os.environ["BEOM_TILE4"] = "1" if tile_rows == 4 else "0"          # (read when a handle is created)
+    try:
+        fold, plain = capi.Engine(f), capi.Engine(f)
+    finally:
+        if old is None: os.environ.pop("BEOM_TILE4")
+        else: os.environ["BEOM_TILE4"] = old
+    assert fold.info("tile_rows") == tile_rows
+    plain.set_option("fold_leith", 0)
+    o = oracle_lib.Oracle(f)
+    for x in (fold, plain, o):
+        x.step(1, 7); x.step(8, 8)
+    a, b = fold.download(), plain.download()
+    for k in ("hlay", "u", "v", "h_u", "h_v", "rs_h", "dmdx", "dmdy"):
+        assert same_bits(a[k], o.state()[k]), (case, k, "folded vs oracle", maxrel(a[k], o.state()[k]))
+        assert same_bits(b[k], o.state()[k]), (case, k, "not folded vs oracle")
+    sa, sb = fold.download_scratch(), plain.download_scratch()
+    assert same(sa["mont"], sb["mont"]) and same(sa["pvor"], sb["pvor"])
+    fold.close(); plain.close()
+
+
+def _forced_cases():
+    """Dense frames with constant layer fractions (ocrp = 0) and a stress refresh on every step (dt3d = 0): the engine forms
+    distribute_stress inside its fused momentum sweep from step 4 on."""
+    from beom_amd import inputs as I
+
+    def basin(nlay, **lits):
+        p, files = I.case_headline(150, 131, nlay)
+        lm, mm = p.lm, p.mm
+        x = np.arange(lm + 2)[:, None] / lm; y = np.arange(mm + 2)[None, :] / mm
+        taus = np.zeros((lm + 2, mm + 2, 2))
+        taus[:, :, 0] = 0.1 * np.cos(np.pi * y) * np.ones_like(x)
+        taus[:, :, 1] = -0.03 * np.sin(2 * np.pi * x) * np.ones_like(y)
+        init = np.array(files["init"], dtype=np.float64)
+        init[:, :, 0, 1] += 0.2 * np.sin(3 * np.pi * y)                 # velocities for the drag to act on, top ...
+        init[:, :, nlay - 1, 2] += -0.1 * np.cos(2 * np.pi * x)         # ... and bottom layer
+        return p.replace(**lits), dict(files, taus=taus, init=init)
+
+    return {
+        "wind_only_2l": lambda: basin(2),
+        "wind_linear_drag_1l": lambda: basin(1, bdrg="2.e-4"),
+        "wind_quadratic_bottom_top_drag_3l": lambda: basin(3, bdrg="3.e-3", tdrg="2.e-3", qdrg="1.", dt_r="0.002"),
+        "bottom_drag_only_3l_bodf": lambda: (lambda pf: (pf[0], dict({k: v for k, v in pf[1].items() if k != "taus"},
+                                                                  bodf=np.array([[1e-7, 0.0], [0.0, 0.0], [0.0, -2e-7]]))))(basin(3, bdrg="1.e-3", qdrg="0.5")),
+        "stommel": lambda: I.case_stommel(lm=150, mm=131, dl=50.0e3, dt_s=0.2),
+        "mixed_open_bc_wind_sponges": lambda: I.case_mixed_open_bc(lm=150, mm=131, npts=15),
+    }
+
+
+@pytest.mark.parametrize("case", ["wind_only_2l", "wind_linear_drag_1l", "wind_quadratic_bottom_top_drag_3l",
+                                  "bottom_drag_only_3l_bodf", "stommel", "mixed_open_bc_wind_sponges"])
+def test_stress_folded_into_momentum_sweep(case):
+    """distribute_stress (private_mod.f95:1921-2149) formed inside the fused u+v sweep: against the oracle, against the same
+    engine with the fold off (its own launch + the three arrays) and on three bands, bit for bit with the sign of zero."""
+    from beom_amd.grid import read_input_data
+    p, files = _forced_cases()[case]()
+    f = read_input_data(p, files=files)
+    obc = bool(f.flag_nudging) and float(p.mcbc) < 0.5
+    fold, plain, o = capi.Engine(f), capi.Engine(f), oracle_lib.Oracle(f)
+    plain.set_option("fold_stress", 0)
+    bands = None if obc else capi.MultiEngine(f, devices=[0, 0, 0])
+    n = 15
+    for x in [fold, plain, o] + ([bands] if bands else []):
+        x.step(1, 3); x.step(4, n - 3)
+    assert fold.info("stress_folded") == 1 and plain.info("stress_folded") == 0
+    a, b = fold.download(), plain.download()
+    for k in ("hlay", "u", "v", "h_u", "h_v", "rs_h", "dmdx", "dmdy"):
+        assert same_bits(a[k], o.state()[k]), (case, k, "folded vs oracle", maxrel(a[k], o.state()[k]))
+        assert same_bits(b[k], o.state()[k]), (case, k, "own launch vs oracle")
+    for k in ("tt3d", "tb3d", "tu3d"):
+        assert same(b[k], o.state()[k]), (case, k)               # kept current only without the fold
+    if bands:
+        assert bands.info("stress_folded") == 1 and bands.stats()["split"] == 3 * n
+        c = bands.download()
+        for k in ("hlay", "u", "v", "h_u", "h_v", "rs_h", "dmdx", "dmdy"):
+            assert same_bits(c[k], o.state()[k]), (case, k, "three bands, folded")
+        bands.close()
+    fold.set_option("keep_diag", 1)                               # keeps the three arrays current again
+    fold.step(n + 1, 2); o.step(n + 1, 2)
+    a = fold.download()
+    assert fold.info("stress_folded") == 0
+    for k in STATE:
+        assert same(a[k], o.state()[k]), (case, k, "keep_diag")
+    fold.close(); plain.close()
 
 
 @pytest.mark.parametrize("case,world", [("closed_3l", 2), ("closed_3l", 3), ("sill_ocrp_nudg_4l", 2),
