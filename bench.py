@@ -41,11 +41,11 @@ B_ALG_KERNEL = {              # per sweep, bytes per cell-layer (SURVEY §8d wor
     "update_h": 7 * 8, "update_mont": 9 * 8, "update_viscosity": 4 * 8, "update_u": 16 * 8, "update_v": 16 * 8,
     # fused launches do the work of two reference sweeps: their algorithmic bytes are the sum
     "update_mont+update_viscosity": (9 + 4) * 8, "update_u+update_v": (16 + 16) * 8,
-    "update_mont+update_viscosity+update_u+update_v": (9 + 4 + 16 + 16) * 8,
+    # the Leith products formed inside the momentum sweep (option "fold_leith"): that launch does the work of three reference sweeps
+    "update_viscosity+update_u+update_v": (4 + 16 + 16) * 8,
 }
-# (with the four-sweep launch active, "update_mont+update_viscosity" is the small launch that prepares the frame's edge tiles)
 KERNEL_ORDER = ("update_h", "update_mont", "update_viscosity", "update_u", "update_v",
-                "update_mont+update_viscosity", "update_u+update_v", "update_mont+update_viscosity+update_u+update_v")
+                "update_mont+update_viscosity", "update_u+update_v", "update_viscosity+update_u+update_v")
 NCLS = len(KERNEL_ORDER)
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec (≈6.3 TB/s achievable)
 

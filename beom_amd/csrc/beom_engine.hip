@@ -50,6 +50,8 @@ void set_err(char *errm, int len, const char *fmt, ...) {
 
 }  // namespace
 
+constexpr int kLidBatch = 256;  // rigid lid: at most this many Gauss-Seidel sweeps in flight at once (lid_solve)
+
 struct StepTimer {        // optional HIP-event bracket around each kernel class
     std::vector<hipEvent_t> ev; std::vector<int> cls;
     hipStream_t st;
@@ -106,6 +108,12 @@ struct beom_engine {
     // rigid lid (rgld = 1): the caller's subc and the packed -> device index map, kept for beom_set_rigid_lid
     std::vector<int32_t> subc_host, neig_host, dev_index;
     bool lid = false, lid_ready = false;
+    // the lid's Gauss-Seidel pipeline (k_rgld_gs_front): time between two sweeps, ring of pressure copies, per-sweep max |change|
+    int lid_dstep = 2, lid_nring = 0, lid_maxwidth = 1;
+    double *lid_ring = nullptr;
+    unsigned long long *lid_maxd = nullptr;
+    long long lid_sweeps = 0, lid_solves = 0, lid_launches = 0;    // statistics (beom_info)
+    int lid_last = 0;                  // sweeps the last solve kept
     int profile_stride = 1;            // option "profile_stride"
     bool profile_rotate = false;       // option "profile_rotate"
     bool split_prod = false;           // split steps: part 1's Montgomery sweep left the viscous products for parts 2 and 3
@@ -649,6 +657,18 @@ int beom_set_rigid_lid(beom_handle E, const double *Ow, const double *Os, const 
                 if (qn > 0 && (size_t)qn > p) after[(size_t)qn] = std::max(after[(size_t)qn], lv + 1);
             nlevel = std::max(nlevel, lv + 1);
         }
+        // time between two sweeps of the pipeline: sweep s + 1 may touch a cell once every neighbour AFTER it in packed order has
+        // been updated by sweep s — 1 + the largest level difference along such an edge (2 on a plain frame; about lm where
+        // a periodic seam makes a cell read the far end of its row)
+        int dstep = 2;
+        for (size_t p = 1; p < n1h; ++p) {
+            const int i = E->subc_host[p], j = E->subc_host[p + n1h];
+            const int32_t *nb = &E->neig_host[8 * p];
+            const int32_t reads[4] = {i < d.lm ? nb[0] : 0, j < d.mm_glob ? nb[2] : 0, i > 1 ? nb[4] : 0, j > 1 ? nb[6] : 0};
+            for (int32_t qn : reads)
+                if (qn > 0 && (size_t)qn > p) dstep = std::max(dstep, level[(size_t)qn] - level[p] + 1);
+        }
+        E->lid_dstep = dstep;
         const int ndiag = nlevel;
         std::vector<int32_t> start((size_t)ndiag + 1, 0), order(n1h > 1 ? n1h - 1 : 1, 0);
         for (size_t p = 1; p < n1h; ++p) ++start[(size_t)level[p] + 1];
@@ -663,6 +683,12 @@ int beom_set_rigid_lid(beom_handle E, const double *Ow, const double *Os, const 
         HIP_TRY(hipMemcpyAsync(q, start.data(), start.size() * sizeof(int32_t), hipMemcpyHostToDevice, E->stream));
         d.sor_dstart = q;
         d.sor_ndiag = ndiag;
+        E->lid_maxwidth = 1;
+        for (int k = 0; k < ndiag; ++k) E->lid_maxwidth = std::max(E->lid_maxwidth, (int)(start[(size_t)k + 1] - start[k]));
+        // one copy of the pressure per sweep in flight: up to kLidBatch of them within ~6 GB
+        E->lid_nring = (int)std::max<long long>(17, std::min<long long>(kLidBatch, (6ll << 30) / ((long long)d.n1 * 8))) + 1;
+        if ((rc = dev_alloc(E, &E->lid_ring, (size_t)E->lid_nring * d.n1, errm, errm_len, true))) return rc;      // zeroed: index 0 and every slot that is no cell stay 0
+        if ((rc = dev_alloc(E, &E->lid_maxd, (size_t)kLidBatch, errm, errm_len, true))) return rc;
         // the terms of every cell's right-hand side in the order of the serial scatter loops (:1727-1752): the x loop over
         // the packed cells, then the y loop; a cell with i > 1 (j > 1) subtracts its transport from itself and adds it to neig(5)
         // (neig(7)); what goes to the sentinel is dropped
@@ -796,12 +822,16 @@ static void launch_uv(beom_engine *E, int ilay, double gene, double ramp, double
 // fused Montgomery + Leith sweep (dense frames); false if no instantiation for this nlay
 // leith: this step refreshes the Leith viscosity (:2188, :2268); else the sweep forms the products of the
 // standing v_cc, v_ll.  keep_visc: a refreshed viscosity has to stand for later steps (n_3d > 1).
+// the Leith products of deep tiles are formed inside the fused u+v sweep (k_uv_fused<.., LF>) instead of k_mont_visc
+static bool leith_folds(const beom_engine *E, bool uv_fused_follows, bool leith, bool keep_visc) {
+    return leith && uv_fused_follows && E->fold_leith && !keep_visc && !E->d.keep_diag;
+}
 static bool launch_mont_visc(beom_engine *E, bool uv_fused_follows, bool leith, bool keep_visc) {
     E->d.lean_d2h = uv_fused_follows && E->lean_d2h && !E->d.keep_diag;
     E->d.keep_visc = keep_visc;
     E->d.zero_visc = !leith && uv_fused_follows && E->lean_visc && E->visc_all_zero && E->P.dvis == 0.0 && E->P.bvis == 0.0 &&
                      !E->d.keep_diag;
-    E->d.prod_in_uv = leith && uv_fused_follows && E->fold_leith && !keep_visc && !E->d.keep_diag;
+    E->d.prod_in_uv = leith_folds(E, uv_fused_follows, leith, keep_visc);
     return E->tile4 ? raw_mont_visc_t4(E, leith) : raw_mont_visc_t8(E, leith);
 }
 // fused U+V sweep (dense frames): first_x = update_u first (even tstp)
@@ -838,10 +868,46 @@ static void launch_lid_fluxes(beom_engine *E, bool first3) {
 static void launch_lid_h_epilogue(beom_engine *E) {
     hipLaunchKernelGGL(k_rgld_h_epilogue, dim3((unsigned)((E->d.ncell + BEOM_BLOCK - 1) / BEOM_BLOCK)), dim3(BEOM_BLOCK), 0, E->stream, E->d);
 }
+// surf_pressure's iteration (:1757-1802): Gauss-Seidel sweeps until max |change| <= 1e-5 or 1000 sweeps, as a pipeline of
+// wavefronts (k_rgld_gs_front): batches of up to kLidBatch sweeps in flight, one launch per time step of the pipeline, the
+// host reads the batch's per-sweep maxima and picks the sweep the serial loop would have stopped after (one small
+// device-to-host copy per batch: a lid step is not asynchronous).
+static int lid_solve(beom_engine *E) {
+    DevView &d = E->d;
+    const int maxiters = 1000;
+    const double pi_tol = 1.e-5;
+    const int R = E->lid_nring, D = E->lid_dstep, nlev = d.sor_ndiag;
+    const size_t bytes = (size_t)d.n1 * sizeof(double);
+    if (hipMemcpyAsync(E->lid_ring, d.pi_s, bytes, hipMemcpyDeviceToDevice, E->stream) != hipSuccess) return -1;      // copy 0 = the pressure before the first sweep
+    // A batch costs (levels + 2 * sweeps) dependent launches whatever it finds, and a launch costs the more the more sweeps are
+    // in flight: the first batch is sized by what the step before needed (+ 25 %), later ones take all the ring holds.
+    int s0 = 1, batch = std::min(R - 1, std::max(16, E->lid_last * 5 / 4 + 8)), chosen = 0;
+    unsigned long long maxd[kLidBatch];
+    while (!chosen) {
+        const int nb = std::min(batch, maxiters - s0 + 1);
+        if (hipMemsetAsync(E->lid_maxd, 0, nb * sizeof(unsigned long long), E->stream) != hipSuccess) return -1;
+        const dim3 g((unsigned)((E->lid_maxwidth + BEOM_BLOCK - 1) / BEOM_BLOCK), (unsigned)nb, 1);
+        const int tend = nlev - 1 + (nb - 1) * D;
+        for (int t = 0; t <= tend; ++t)
+            hipLaunchKernelGGL(k_rgld_gs_front, g, dim3(BEOM_BLOCK), 0, E->stream, d, E->lid_ring, R, s0, t, D, E->lid_maxd);
+        E->lid_launches += tend + 1;
+        if (hipMemcpyAsync(maxd, E->lid_maxd, nb * sizeof(unsigned long long), hipMemcpyDeviceToHost, E->stream) != hipSuccess) return -1;
+        if (hipStreamSynchronize(E->stream) != hipSuccess) return -1;
+        for (int b = 0; b < nb && !chosen; ++b) {
+            double m; memcpy(&m, &maxd[b], sizeof(double));
+            if (!(m > pi_tol) || s0 + b == maxiters) chosen = s0 + b;           // `do while (maxdiff > pi_tol .and. iters < maxiters)`
+        }
+        s0 += nb;
+        batch = R - 1;
+    }
+    E->lid_sweeps += chosen; ++E->lid_solves; E->lid_last = chosen;
+    if (hipMemcpyAsync(d.pi_s, E->lid_ring + (size_t)(chosen % R) * d.n1, bytes, hipMemcpyDeviceToDevice, E->stream) != hipSuccess) return -1;
+    return 0;
+}
 static void launch_lid_pressure(beom_engine *E) {
     const dim3 g1((unsigned)((E->d.ncell + BEOM_BLOCK - 1) / BEOM_BLOCK)), g((unsigned)((E->d.ncell + BEOM_BLOCK - 1) / BEOM_BLOCK), (unsigned)E->d.nlay, 1);
     hipLaunchKernelGGL(k_rgld_rhs, g1, dim3(BEOM_BLOCK), 0, E->stream, E->d);
-    hipLaunchKernelGGL(k_rgld_sor, dim3(1), dim3(SOR_THREADS), 0, E->stream, E->d);
+    if (lid_solve(E)) snprintf(E->last_err, sizeof(E->last_err), "the lid's pressure iteration failed: %s", hipGetErrorString(hipGetLastError()));
     hipLaunchKernelGGL(k_rgld_correct, g, dim3(BEOM_BLOCK), 0, E->stream, E->d);
 }
 static void launch_stress(beom_engine *E) {
@@ -913,7 +979,10 @@ static void one_step(beom_engine *E, int tstp, const StepScalars &s) {
     if (E->lid) launch_lid_h_epilogue(E);                          // :1648-1700
     const bool leith = E->P.dvis > 1.e-3 && s.upst;
     const bool u_first = tstp % 2 == 0;                            // :2193-2199,2276-2282
-    if (T) { T->end(); T->begin(s.fused ? 5 : 1); }
+    // timer classes: with the Leith products formed in the u+v sweep, the Montgomery launch counts as update_mont (1) and the
+    // momentum launch as update_viscosity + update_u + update_v (7)
+    const bool lf = s.fused && leith_folds(E, s.fused_uv, leith, leith && s.n_3d > 1);
+    if (T) { T->end(); T->begin(s.fused && !lf ? 5 : 1); }
     const bool prod = s.fused && launch_mont_visc(E, s.fused_uv, leith, leith && s.n_3d > 1);              // :2187-2188, 2266-2269 in one sweep
     if (!prod) launch_mont(E, 0);
     if (T) T->end();
@@ -923,7 +992,7 @@ static void one_step(beom_engine *E, int tstp, const StepScalars &s) {
         if (T) T->end();
     }
     if (s.fused_uv) {
-        if (T) T->begin(6);
+        if (T) T->begin(lf && prod ? 7 : 6);
         launch_uv_fused(E, u_first, prod, s.gene, s.ramp, s.ctim);
         if (T) T->end();
     } else if (u_first) {
@@ -1055,7 +1124,7 @@ int beom_step_phase(beom_handle E, int tstp, double tres, double dtd8, double dt
         if (T) T->begin(0);
         launch_h(E, s.gene, s.ramp, s.ctim);                           // :2181,2259
         const bool leith = E->P.dvis > 1.e-3 && s.upst;
-        if (T) { T->end(); T->begin(s.fused ? 5 : 1); }
+        if (T) { T->end(); T->begin(s.fused && !leith_folds(E, true, leith, leith && s.n_3d > 1) ? 5 : 1); }
         E->split_prod = s.fused && launch_mont_visc(E, true, leith, leith && s.n_3d > 1);
         if (!E->split_prod) launch_mont(E, 0);
         if (T) T->end();
@@ -1069,12 +1138,12 @@ int beom_step_phase(beom_handle E, int tstp, double tres, double dtd8, double dt
         if (south && north) set_rows(d, 2, 1, kEdgeRows, M - kEdgeRows + 1, M);
         else if (south) set_rows(d, 1, 1, kEdgeRows);
         else set_rows(d, 1, M - kEdgeRows + 1, M);
-        if (T) T->begin(6);
+        if (T) T->begin(E->split_prod && d.prod_in_uv ? 7 : 6);
         launch_uv_fused(E, u_first, E->split_prod, s.gene, s.ramp, s.ctim, false);
         if (T) T->end();
     } else {
         set_rows(d, 1, south ? kEdgeRows + 1 : 1, north ? M - kEdgeRows : M);
-        if (T) T->begin(6);
+        if (T) T->begin(E->split_prod && d.prod_in_uv ? 7 : 6);
         launch_uv_fused(E, u_first, E->split_prod, s.gene, s.ramp, s.ctim, true);
         if (T) T->end();
     }
@@ -1227,6 +1296,10 @@ int beom_info(beom_handle E, const char *what) {
     if (!E || !what) return -1;
     if (!strcmp(what, "stress_folded")) return E->last_folded ? 1 : 0;
     if (!strcmp(what, "tile_rows")) return E->dense ? (E->tile4 ? 4 : 8) : 0;
+    if (!strcmp(what, "lid_sweeps")) return (int)std::min<long long>(E->lid_sweeps, 2000000000ll);        // Gauss-Seidel sweeps kept, all steps so far
+    if (!strcmp(what, "lid_solves")) return (int)std::min<long long>(E->lid_solves, 2000000000ll);
+    if (!strcmp(what, "lid_launches")) return (int)std::min<long long>(E->lid_launches, 2000000000ll);
+    if (!strcmp(what, "lid_sweep_distance")) return E->lid_dstep;
     return -3;
 }
 

@@ -921,9 +921,25 @@ __device__ __forceinline__ void body_uv_fused_staged(const DevView &d, int x0, i
     // ZV (zero viscosity): pcd, qlr are neither staged nor read; LF: they are formed below, not loaded
     constexpr int NF = (ZV || LF) ? 2 : 4;
     const double *src[5] = {d.mont, d.pvor, (ZV || LF) ? d.hlay : d.pcd, (ZV || LF) ? d.hlay : d.qlr, d.hlay};
-    constexpr int NUV = LF ? UV_UROWS * UV_UCOLS : 1, NITU = (NUV + UV_BLOCK - 1) / UV_BLOCK;
+#ifndef UV_LF_DIRECT
+#define UV_LF_DIRECT 0      // 0: u, v of tile + 3 staged in LDS first; 1: rvor, dive of tile + 2 straight from global u, v (6 loads
+                            //    per point, issued with the other loads of the phase: two barriers less, 24 more VGPRs)
+#endif
+    constexpr int NUV = (LF && !UV_LF_DIRECT) ? UV_UROWS * UV_UCOLS : 1, NITU = (NUV + UV_BLOCK - 1) / UV_BLOCK;
     double uu[NITU], vv[NITU];
-    if (LF) {
+    constexpr int NRV = LF ? UV_RROWS * UV_RCOLS : 1, NITR = (NRV + UV_BLOCK - 1) / UV_BLOCK;
+    double w6[NITR][6];
+    if (LF && UV_LF_DIRECT) {
+#pragma unroll
+        for (int k = 0; k < NITR; ++k) {
+            const int idx = tid + k * UV_BLOCK;
+            const int idc = idx < NRV ? idx : tid;
+            const int r2 = idc / UV_RCOLS, c2 = idc - r2 * UV_RCOLS;
+            const long long ip = (long long)(x0 - 2 + c2) + (long long)(y0 - 3 + r2) * d.P + lay;     // cell (x0-2+c2, y0-2+r2)
+            w6[k][0] = d.u[ip]; w6[k][1] = d.u[ip + 1]; w6[k][2] = d.v[ip]; w6[k][3] = d.v[ip + d.P];     // u, u(E), v, v(N)
+            w6[k][4] = d.v[ip - 1]; w6[k][5] = d.u[ip - d.P];                                             // v(W), u(S)
+        }
+    } else if (LF) {
 #pragma unroll
         for (int k = 0; k < NITU; ++k) {
             const int idx = tid + k * UV_BLOCK;
@@ -983,26 +999,33 @@ __device__ __forceinline__ void body_uv_fused_staged(const DevView &d, int x0, i
     }
     if (hrr >= 0) s_hl[hrr][hcc] = hring;
     if (LF) {
-        double (*su)[UV_UCOLS] = (double (*)[UV_UCOLS])s_uv, (*sv)[UV_UCOLS] = su + UV_UROWS;
-#pragma unroll
-        for (int k = 0; k < NITU; ++k) {
-            const int idx = tid + k * UV_BLOCK;
-            if (idx < NUV) { const int rr = idx / UV_UCOLS, cc = idx - rr * UV_UCOLS; su[rr][cc] = uu[k]; sv[rr][cc] = vv[k]; }
-        }
-        __syncthreads();
-        // rvor, dive of the cells (x0-2+c2, y0-2+r2): update_mont's expressions with mkpe = 1 (rv_dv_calc)
-        constexpr int NRV = UV_RROWS * UV_RCOLS, NITR = (NRV + UV_BLOCK - 1) / UV_BLOCK;
         double rvv[NITR], dvv[NITR];
+        if (UV_LF_DIRECT) {
+            // rvor, dive of the cells (x0-2+c2, y0-2+r2): update_mont's expressions with mkpe = 1 (rv_dv_calc)
 #pragma unroll
-        for (int k = 0; k < NITR; ++k) {
-            const int idx = tid + k * UV_BLOCK;
-            const int idc = idx < NRV ? idx : tid;
-            const int r2 = idc / UV_RCOLS, c2 = idc - r2 * UV_RCOLS;
-            const double u0 = su[r2 + 1][c2 + 1], v0 = sv[r2 + 1][c2 + 1];
-            rvv[k] = (v0 - sv[r2 + 1][c2] - u0 + su[r2][c2 + 1]) * d.i_dl * 1.0;
-            dvv[k] = (su[r2 + 1][c2 + 2] - u0 + sv[r2 + 2][c2 + 1] - v0) * d.i_dl;
+            for (int k = 0; k < NITR; ++k) {
+                rvv[k] = (w6[k][2] - w6[k][4] - w6[k][0] + w6[k][5]) * d.i_dl * 1.0;
+                dvv[k] = (w6[k][1] - w6[k][0] + w6[k][3] - w6[k][2]) * d.i_dl;
+            }
+        } else {
+            double (*su)[UV_UCOLS] = (double (*)[UV_UCOLS])s_uv, (*sv)[UV_UCOLS] = su + UV_UROWS;
+#pragma unroll
+            for (int k = 0; k < NITU; ++k) {
+                const int idx = tid + k * UV_BLOCK;
+                if (idx < NUV) { const int rr = idx / UV_UCOLS, cc = idx - rr * UV_UCOLS; su[rr][cc] = uu[k]; sv[rr][cc] = vv[k]; }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < NITR; ++k) {
+                const int idx = tid + k * UV_BLOCK;
+                const int idc = idx < NRV ? idx : tid;
+                const int r2 = idc / UV_RCOLS, c2 = idc - r2 * UV_RCOLS;
+                const double u0 = su[r2 + 1][c2 + 1], v0 = sv[r2 + 1][c2 + 1];
+                rvv[k] = (v0 - sv[r2 + 1][c2] - u0 + su[r2][c2 + 1]) * d.i_dl * 1.0;
+                dvv[k] = (su[r2 + 1][c2 + 2] - u0 + sv[r2 + 2][c2 + 1] - v0) * d.i_dl;
+            }
+            __syncthreads();                              // every thread has read the velocities it needs
         }
-        __syncthreads();                                  // every thread has read the velocities it needs
         double (*srv)[UV_RLDX] = (double (*)[UV_RLDX])s_uv, (*sdv)[UV_RLDX] = srv + UV_RROWS;
 #pragma unroll
         for (int k = 0; k < NITR; ++k) {
@@ -1010,9 +1033,12 @@ __device__ __forceinline__ void body_uv_fused_staged(const DevView &d, int x0, i
             if (idx < NRV) { const int r2 = idx / UV_RCOLS, c2 = idx - r2 * UV_RCOLS; srv[r2][c2] = rvv[k]; sdv[r2][c2] = dvv[k]; }
         }
         __syncthreads();
-        // the products at the stage positions (x0-1+c1, y0-1+r1); names as in update_viscosity (:2458-2470)
+        // the products at the stage positions (x0-1+c1, y0-1+r1); names as in update_viscosity (:2458-2470).  Into registers
+        // first: their stage slots share LDS memory with rvor / dive (k_uv_fused)
+        double pcdv[NIT], qlrv[NIT];
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
+            pcdv[k] = 0.0; qlrv[k] = 0.0;
             if (tid + k * UV_BLOCK >= NST) continue;
             const int r = frr[k] + 1, cx = fcc[k] + 1;
             const double r_bl = srv[r][cx], r_br = srv[r][cx + 1], r_tr = srv[r + 1][cx + 1], r_tl = srv[r + 1][cx],
@@ -1029,9 +1055,13 @@ __device__ __forceinline__ void body_uv_fused_staged(const DevView &d, int x0, i
                            + (d_ri - d_cc) * (d_ri - d_cc) + (d_cc - d_le) * (d_cc - d_le)
                            + (d_to - d_cc) * (d_to - d_cc) + (d_cc - d_bo) * (d_cc - d_bo);
             const double vcc = sqrt(b) * d.dvis * d.dl * d.dl + d.bvis;
-            s_f[2][frr[k]][fcc[k]] = vcc * d_cc;
-            s_f[3][frr[k]][fcc[k]] = vll * r_bl;
+            pcdv[k] = vcc * d_cc;
+            qlrv[k] = vll * r_bl;
         }
+        __syncthreads();                                  // every thread has read the rvor, dive it needs
+#pragma unroll
+        for (int k = 0; k < NIT; ++k)
+            if (tid + k * UV_BLOCK < NST) { s_f[2][frr[k]][fcc[k]] = pcdv[k]; s_f[3][frr[k]][fcc[k]] = qlrv[k]; }
     }
     __syncthreads();
     // ---- phase B loads (second update): in flight while the first update is evaluated
@@ -1288,12 +1318,33 @@ __device__ __forceinline__ void body_uv_fused_edge(const DevView &d, int x0, int
 #else
 #define UV_OCC_ATTR
 #endif
-template <bool FIRST_X, bool PROD, bool ZV = false, bool LF = false>
-__global__ __launch_bounds__(UV_BLOCK) UV_OCC_ATTR void k_uv_fused(DevView d, double gene, double ramp, double ctim) {
-    __shared__ double s_h[UV_TY + 1][UV_LDX];
-    __shared__ UVstage s_f[PROD ? 4 : 1];                    // (ZV: the interior workgroups use two of them, the edge ones all four)
+// LDS of one workgroup: [mont | pvor | pcd | qlr] stages, the first update's transports, the wider hlay stage.  LF: the
+// staged velocities (tile + 3), later rvor / dive (tile + 2), live in the memory of pcd | qlr | transports, which are
+// written only after them — the fold costs no LDS, so four workgroups still fit a CU (three cost the sweep 9 %: measured
+// with 14 KB of unused LDS, profiles/r03_leith_fold.txt).
+#define UV_STAGE_N (UV_SROWS * UV_SLDX)
+#define UV_SH_N ((UV_TY + 1) * UV_LDX)
+#define UV_OV_N (UV_LF_DIRECT ? 2 * UV_RROWS * UV_RLDX : 2 * UV_UROWS * UV_UCOLS)
+#define UV_BUF_N ((2 * UV_STAGE_N + UV_OV_N) > (4 * UV_STAGE_N + UV_SH_N) ? (2 * UV_STAGE_N + UV_OV_N) : (4 * UV_STAGE_N + UV_SH_N))
+#ifndef UV_LF_WAVES_PER_EU
+#define UV_LF_WAVES_PER_EU 4          // the folded form would take 134 VGPRs (three waves per SIMD) left alone
+#endif
+#if UV_LF_WAVES_PER_EU > 0
+#define UV_LF_OCC_ATTR __attribute__((amdgpu_waves_per_eu(UV_LF_WAVES_PER_EU)))
+#else
+#define UV_LF_OCC_ATTR
+#endif
+template <bool FIRST_X, bool PROD, bool ZV, bool LF>
+__device__ __forceinline__ void uv_fused_kernel_body(const DevView &d, double gene, double ramp, double ctim) {
+    __shared__ double s_buf[PROD ? UV_BUF_N : UV_SH_N + UV_STAGE_N];
     __shared__ double s_hl[PROD ? UV_HROWS : 1][UV_HLDX];
-    __shared__ double s_uv[LF ? 2 * UV_UROWS * UV_UCOLS : 1];   // LF: u, v of tile + 3, then rvor, dive of tile + 2
+    UVstage *s_f = (UVstage *)s_buf;                        // (ZV: the interior workgroups use two of them, the edge ones all four)
+    double (*s_h)[UV_LDX] = (double (*)[UV_LDX])(s_buf + (PROD ? 4 : 1) * UV_STAGE_N);
+    double *s_uv = s_buf + 2 * UV_STAGE_N;                   // LF: (u, v of tile + 3, then) rvor, dive of tile + 2
+#ifdef UV_PAD_LDS        // (experiment: what the occupancy of three workgroups per CU alone costs the sweep)
+    __shared__ double s_pad[UV_PAD_LDS / 8];
+    if (gene == -12345.0) s_pad[threadIdx.x] = ramp;
+#endif
     const TileMap tm(d, UV_TX, UV_TY);
     int ty, ch;
     if (!tm.locate(blockIdx.x, ty, ch)) return;
@@ -1305,6 +1356,15 @@ __global__ __launch_bounds__(UV_BLOCK) UV_OCC_ATTR void k_uv_fused(DevView d, do
     else if (interior) body_uv_fused<FIRST_X, PROD, true>(d, x0, y0, ilay, gene, ramp, ctim, s_h);
     else if (PROD && !d.edge_global) body_uv_fused_edge<FIRST_X>(d, x0, y0, ilay, gene, ramp, ctim, s_h, s_f, s_hl);
     else body_uv_fused<FIRST_X, PROD, false>(d, x0, y0, ilay, gene, ramp, ctim, s_h);
+}
+template <bool FIRST_X, bool PROD, bool ZV = false>
+__global__ __launch_bounds__(UV_BLOCK) UV_OCC_ATTR void k_uv_fused(DevView d, double gene, double ramp, double ctim) {
+    uv_fused_kernel_body<FIRST_X, PROD, ZV, false>(d, gene, ramp, ctim);
+}
+// ... with the Leith products of interior tiles formed inside (option "fold_leith")
+template <bool FIRST_X>
+__global__ __launch_bounds__(UV_BLOCK) UV_LF_OCC_ATTR void k_uv_fused_lf(DevView d, double gene, double ramp, double ctim) {
+    uv_fused_kernel_body<FIRST_X, true, false, true>(d, gene, ramp, ctim);
 }
 static inline dim3 uv_fused_grid(const DevView &d) {
     return dim3(TileMap(d, UV_TX, UV_TY).blocks(), (unsigned)d.nlay, 1);
@@ -1647,47 +1707,41 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_rgld_rhs(DevView d) {
         }
     d.pi_rhs[ipnt] = r;
 }
-// Gauss-Seidel sweeps in packed order (rp = 1, :1757-1802) as wavefronts over the levels of the serial sweep's dependency
-// graph (beom_set_rigid_lid; on a plain frame the anti-diagonals i + j): a cell reads the NEW pressure of the neighbours
-// before it in packed order and the OLD one of those after it, exactly what the serial loop does.  ONE workgroup (the whole
-// iteration, convergence test included, stays on the device): meant for the small frames this option is run on.
-#define SOR_THREADS 1024
-__global__ __launch_bounds__(SOR_THREADS) void k_rgld_sor(DevView d) {
-    __shared__ double s_red[SOR_THREADS / 64];
-    __shared__ double s_max;
-    const double rp = 1.000, pi_tol = 1.e-5;
-    const int maxiters = 1000, tid = threadIdx.x;
-    double maxdiff = pi_tol + 1;
-    int iters = 0;
-    while (maxdiff > pi_tol && iters < maxiters) {
-        double mine = 0.0;
-        for (int dg = 0; dg < d.sor_ndiag; ++dg) {
-            for (int k = d.sor_dstart[dg] + tid; k < d.sor_dstart[dg + 1]; k += SOR_THREADS) {
-                const int ipnt = d.sor_order[k];
-                const int i = d.subc[ipnt], j = d.subc[ipnt + d.n1];
-                const int32_t *nb = d.neig + 8ll * ipnt;
-                const double old = d.pi_s[ipnt], os_ = d.Osum_[ipnt];
-                double x = (1 - rp) * old - rp * os_ * d.pi_rhs[ipnt];
-                if (i < d.lm) { const int c1 = nb[0]; x = x + rp * os_ * d.Ow[c1] * d.pi_s[c1]; }
-                if (j < d.mm) { const int c3 = nb[2]; x = x + rp * os_ * d.Os[c3] * d.pi_s[c3]; }
-                if (i > 1) { const int c5 = nb[4]; x = x + rp * os_ * d.Ow[ipnt] * d.pi_s[c5]; }
-                if (j > 1) { const int c7 = nb[6]; x = x + rp * os_ * d.Os[ipnt] * d.pi_s[c7]; }
-                d.pi_s[ipnt] = x;
-                const double diff = fabs(x - old);
-                if (diff > mine) mine = diff;
-            }
-            __threadfence_block();
-            __syncthreads();
-        }
-        for (int off = 32; off > 0; off >>= 1) mine = fmax(mine, __shfl_down(mine, off, 64));
-        if ((tid & 63) == 0) s_red[tid >> 6] = mine;
-        __syncthreads();
-        if (tid == 0) { double m = s_red[0]; for (int w = 1; w < SOR_THREADS / 64; ++w) m = fmax(m, s_red[w]); s_max = m; }
-        __syncthreads();
-        maxdiff = s_max;
-        iters = iters + 1;
-        __syncthreads();
+// Gauss-Seidel sweeps in packed order (rp = 1, :1757-1802), the serial arithmetic kept: a cell reads the NEW pressure of the
+// neighbours before it in packed order and the OLD one of those after it.  That is a dependency graph; its levels within one
+// sweep (beom_set_rigid_lid; on a plain frame the anti-diagonals i + j) say which cells may be updated side by side, and a
+// cell of sweep s + 1 only needs the cells of sweep s one level further on — so SEVERAL SWEEPS ARE IN FLIGHT AT ONCE, a
+// pipeline of wavefronts: cell p of sweep s runs at time level(p) + (s - s0) * D (D = 1 + the largest level difference along
+// an edge: 2 on a plain frame).  Every sweep writes its own copy of the pressure (a ring of B + 1 copies; sweep s reads copy
+// s for the neighbours before p and copy s - 1 for those after p and for p itself), so the sweeps that run on past the one
+// the convergence test picks leave that one intact.  One launch per time step: blockIdx.y = the sweep of the batch, the
+// blocks of a sweep cover its level at that time.  maxd[b] = max |change| of sweep s0 + b (bit pattern of a non-negative
+// double: ordered like the unsigned integer).
+__global__ __launch_bounds__(BEOM_BLOCK) void k_rgld_gs_front(DevView d, double *ring, int nring, int s0, int t, int dstep,
+                                                               unsigned long long *maxd) {
+    const int b = blockIdx.y, lev = t - b * dstep;
+    if (lev < 0 || lev >= d.sor_ndiag) return;
+    const int k = d.sor_dstart[lev] + blockIdx.x * BEOM_BLOCK + threadIdx.x;
+    double diff = 0.0;
+    if (k < d.sor_dstart[lev + 1]) {
+        const double rp = 1.000;
+        const int s = s0 + b;
+        double *cur = ring + (long long)(s % nring) * d.n1;
+        const double *prv = ring + (long long)((s - 1) % nring) * d.n1;
+        const int ipnt = d.sor_order[k];
+        const int i = d.subc[ipnt], j = d.subc[ipnt + d.n1];
+        const int32_t *nb = d.neig + 8ll * ipnt;
+        const double old = prv[ipnt], os_ = d.Osum_[ipnt];
+        double x = (1 - rp) * old - rp * os_ * d.pi_rhs[ipnt];
+        if (i < d.lm) { const int c1 = nb[0]; x = x + rp * os_ * d.Ow[c1] * (c1 < ipnt ? cur : prv)[c1]; }
+        if (j < d.mm) { const int c3 = nb[2]; x = x + rp * os_ * d.Os[c3] * (c3 < ipnt ? cur : prv)[c3]; }
+        if (i > 1) { const int c5 = nb[4]; x = x + rp * os_ * d.Ow[ipnt] * (c5 < ipnt ? cur : prv)[c5]; }
+        if (j > 1) { const int c7 = nb[6]; x = x + rp * os_ * d.Os[ipnt] * (c7 < ipnt ? cur : prv)[c7]; }
+        cur[ipnt] = x;
+        diff = fabs(x - old);
     }
+    for (int off = 32; off > 0; off >>= 1) diff = fmax(diff, __shfl_down(diff, off, 64));
+    if ((threadIdx.x & 63) == 0 && diff > 0.0) atomicMax(&maxd[b], (unsigned long long)__double_as_longlong(diff));
 }
 __global__ __launch_bounds__(BEOM_BLOCK) void k_rgld_correct(DevView d) {                    // :1806-1833
     const int ipnt = blockIdx.x * BEOM_BLOCK + threadIdx.x + 1;

@@ -20,8 +20,8 @@ static void TFN(raw_uv_fused)(beom_engine *E, bool first_x, bool prod, bool zv, 
     const dim3 g = TNS::uv_fused_grid(E->d), b(TNS::kUvBlock);
     DevView &d = E->d;
     if (prod && !zv && d.prod_in_uv) {            // the Leith products are formed inside the sweep
-        if (first_x) hipLaunchKernelGGL((TNS::k_uv_fused<true, true, false, true>), g, b, 0, E->stream, d, gene, ramp, ctim);
-        else hipLaunchKernelGGL((TNS::k_uv_fused<false, true, false, true>), g, b, 0, E->stream, d, gene, ramp, ctim);
+        if (first_x) hipLaunchKernelGGL((TNS::k_uv_fused_lf<true>), g, b, 0, E->stream, d, gene, ramp, ctim);
+        else hipLaunchKernelGGL((TNS::k_uv_fused_lf<false>), g, b, 0, E->stream, d, gene, ramp, ctim);
         return;
     }
     if (first_x) {

@@ -423,10 +423,10 @@ int check_frame(const beom_params *prm, int nb, int yper, bool global_arrays, bo
     const int ring_rows = yper ? prm->mm : Mg;
     // every band sends its outermost kGhost owned rows; band 0 of a ring also lends rows 1..kMiniLo to the companion frame
     if (ring_rows < nb * (yper ? (kGhost > kMiniLo ? kGhost : kMiniLo) : kGhost + 1)) { m_err(errm, errm_len, "beom_multi: %d rows are too few for %d bands", ring_rows, nb); return -3; }
-    if (prm->flag_nudging && prm->mcbc < 0.5 && (!global_arrays || yper)) {
+    if (prm->flag_nudging && prm->mcbc < 0.5 && !global_arrays) {
         // (the segment table is made of global cell indices: beom_multi_set_open_boundaries deals it to the bands of a handle
-        //  created from the global arrays; not for a ring of bands)
-        m_err(errm, errm_len, "beom_multi: mcbc = 0 (no_gradient_obc) needs a handle created from the global arrays of a frame not periodic in y");
+        //  created from the global arrays — a chain or a ring; a rank that holds only its window has no such table)
+        m_err(errm, errm_len, "beom_multi: mcbc = 0 (no_gradient_obc) needs a handle created from the global arrays");
         return -4;
     }
     if (yper && prm->svis > 0.0) { m_err(errm, errm_len, "beom_multi: biharmonic viscosity on a frame periodic in y runs on a single-device handle only"); return -4; }
@@ -1055,36 +1055,45 @@ int beom_multi_download_outputs(beom_multi_handle M, const float *h0r4, float *e
 // (such steps are not split: the exchange follows the whole step).
 int beom_multi_set_open_boundaries(beom_multi_handle M, int nseg, const int32_t *segm, char *errm, int errm_len) {
     if (!M || nseg < 1 || !segm) { m_err(errm, errm_len, "beom_multi_set_open_boundaries: bad arguments"); return -1; }
-    if (M->local_mode || M->ring) { m_err(errm, errm_len, "beom_multi_set_open_boundaries: needs a handle created from the global arrays of a frame not periodic in y"); return -3; }
-    if (M->nb == 1) return beom_set_open_boundaries(M->eng[0], nseg, segm, errm, errm_len);
+    if (M->local_mode) { m_err(errm, errm_len, "beom_multi_set_open_boundaries: needs a handle created from the global arrays"); return -3; }
+    if (M->land) { m_err(errm, errm_len, "beom_multi_set_open_boundaries: not for bands of a frame with land"); return -3; }
+    if (M->nb == 1 && !M->ring) return beom_set_open_boundaries(M->eng[0], nseg, segm, errm, errm_len);
     const int L = M->P.lm + 1;
     auto S = [&](int is, int col) { return segm[(size_t)is + (size_t)nseg * (col - 1)]; };
-    for (int k = 0; k < M->n; ++k) {
-        const Band &b = M->band[k];
-        const int row0 = b.own0 - b.gs;                                     // global row of local row 1
-        // global cell index -> index in the band's window; 0 stays the sentinel; -1: outside the window
-        auto local = [&](int32_t q) -> int32_t {
-            if (q <= 0) return q == 0 ? 0 : -1;
-            const int j = (q - 1) / L + 1, i = (q - 1) % L + 1, jl = j - row0 + 1;
-            return (jl >= 1 && jl <= b.rows()) ? (int32_t)(i + (long long)(jl - 1) * L) : -1;
-        };
-        std::vector<int> keep;
+    // k = -1: the companion frame of a ring (rows 1..6, mm-3..mm, mm+1 — it holds the orphan row's end of every segment)
+    for (int k = M->mini ? -1 : 0; k < M->n; ++k) {
+        const std::vector<int> wrows = k < 0 ? M->mini_rows : M->band[k].row_list();   // global row of every local row (a ring's ghosts wrap)
+        // A pass of a segment (its updated cell: column 10 for the first pass, 1 for the second; its source cell: 16 / 13) goes
+        // to EVERY local row that holds the updated cell's global row — in a ring a row can be there twice, owned and as a
+        // wrapped ghost — with the source cell taken from the local row next to it (or itself) that holds the source's row.
         std::vector<std::array<int32_t, 18>> rowsv;
-        for (int is = 0; is < nseg; ++is) {
-            std::array<int32_t, 18> r;
-            for (int c = 1; c <= 18; ++c) r[(size_t)c - 1] = S(is, c);
-            for (int c : {1, 7, 10, 13, 16}) r[(size_t)c - 1] = local(S(is, c));
-            if (r[9] == -1 || r[15] == -1) { r[9] = -1; r[15] = 0; }        // pass 0: updated cell (10), source (16)
-            if (r[0] == -1 || r[12] == -1) { r[0] = -1; r[12] = 0; }        // pass 1: updated cell (1), source (13)
-            if (r[6] == -1) r[6] = 0;                                       // (column 7 is not read on the device)
-            if (r[9] == -1 && r[0] == -1) continue;
-            rowsv.push_back(r);
-        }
+        auto row_of = [&](int32_t q) { return (q - 1) / L + 1; };
+        auto col_of = [&](int32_t q) { return (q - 1) % L + 1; };
+        for (int is = 0; is < nseg; ++is)
+            for (int pass = 0; pass < 2; ++pass) {
+                const int cu = pass == 0 ? 10 : 1, cs = pass == 0 ? 16 : 13;
+                const int32_t qu = S(is, cu), qs = S(is, cs);
+                if (qu < 1) continue;
+                for (size_t jl = 0; jl < wrows.size(); ++jl) {
+                    if (wrows[jl] != row_of(qu)) continue;
+                    int32_t src = qs == 0 ? 0 : -1;
+                    if (qs > 0)
+                        for (long long js = (long long)jl - 1; js <= (long long)jl + 1; ++js)
+                            if (js >= 0 && js < (long long)wrows.size() && wrows[(size_t)js] == row_of(qs)) { src = (int32_t)(col_of(qs) + js * L); break; }
+                    if (src < 0) continue;                                   // the source's row is not next to this copy of the row: another band's
+                    std::array<int32_t, 18> r;
+                    for (int c = 1; c <= 18; ++c) r[(size_t)c - 1] = S(is, c);
+                    r[0] = r[9] = -1; r[12] = r[15] = r[6] = 0;              // both passes off, then this one on
+                    r[(size_t)cu - 1] = (int32_t)(col_of(qu) + (long long)jl * L);
+                    r[(size_t)cs - 1] = src;
+                    rowsv.push_back(r);
+                }
+            }
         const int nloc = (int)rowsv.size();
         std::vector<int32_t> tab((size_t)nloc * 18);
         for (int is = 0; is < nloc; ++is)
             for (int c = 0; c < 18; ++c) tab[(size_t)is + (size_t)nloc * c] = rowsv[(size_t)is][(size_t)c];
-        M_RC(beom_set_open_boundaries(M->eng[k], nloc, nloc ? tab.data() : nullptr, errm, errm_len));
+        M_RC(beom_set_open_boundaries(k < 0 ? M->mini : M->eng[k], nloc, nloc ? tab.data() : nullptr, errm, errm_len));
     }
     return 0;
 }

@@ -146,6 +146,35 @@ def case_obc():
     return p, {"h_bo": h_bo, "nudg": nudg, "init": init}
 
 
+def case_obc_yper():
+    """no_gradient_obc (mcbc = 0) on a channel periodic in y: a nudged western and a nudged eastern open boundary whose
+    segments run through the periodic seam and the orphan row mm+1 (:642-668, :1060-1240, :2613-2679)."""
+    lm, mm, nlay = 30, 27, 2
+    h_bo = np.zeros((lm + 2, mm + 2)); h_bo[1:-1, :] = 120.0
+    ndeg = I.get_nbr_deg_freedom(h_bo)
+    nudg = np.zeros((lm + 2, mm + 2, 3))
+    for i in range(0, 7):                       # western sponge: eta and u (normal), margin included
+        nudg[i, :, 0] = 0.35 * (7 - i) / 7.0
+        nudg[i, :, 1] = 0.35 * (7 - i) / 7.0
+    for i in range(lm + 1, lm - 5, -1):         # eastern sponge
+        w = 0.3 * (i - (lm - 5)) / 7.0
+        nudg[i, :, 0] = np.maximum(nudg[i, :, 0], w)
+        nudg[i, :, 1] = np.maximum(nudg[i, :, 1], w)
+    x = (np.arange(lm + 2) - 14.0)[:, None]; y = (np.arange(mm + 2) - 9.0)[None, :]
+    init = np.zeros((lm + 2, mm + 2, nlay, 3))
+    init[:, :, 0, 0] = 0.5 * np.exp(-(x ** 2 + y ** 2) / 9.0)
+    init[:, :, 1, 0] = -2.0 * np.exp(-(x ** 2 + y ** 2) / 9.0)
+    init[:, :, 0, 1] = 0.02
+    init[:, :, 1, 2] = 0.01 * np.sin(2 * np.pi * np.arange(mm + 2) / mm)[None, :]
+    for a_ in (init,):                          # periodic margins in y
+        a_[:, 0] = a_[:, mm]; a_[:, mm + 1] = a_[:, 1]
+    cext = np.sqrt(9.8 * 120.0); dl = 3.0e3; dt = 0.5 * dl / cext
+    p = make_params(lm, mm, nlay, ndeg, dl, cext, 0.8e-4, [1025.0, 1027.5], [0.0, 0.35],
+                    12 * dt / 86400.0, 4 * dt / 86400.0, 0.0, 0.0, 0.0, 0.15, 0.0, 1.0, 10.0, 10.0, 1.0, 1.0,
+                    0.0, 0.0, 0.0, 0.0, 1.0, 0.0, desc="golden: open boundaries mcbc = 0, periodic in y", mcbc="0.")
+    return p, {"h_bo": h_bo, "nudg": nudg, "init": init}
+
+
 def case_biharm():
     """Biharmonic viscosity svis > 0 (private_mod.f95:2508-2599, 1471-1473, 1555-1557) on the
     island basin: every land-mask combination meets the masked Laplacians."""
@@ -242,6 +271,7 @@ CASES = {
     "variant3d_3l": (case_3d_variant, "private_mod3d.f95"),
     "obc_mcbc0_2l": (case_obc, "private_mod.f95"),
     "biharm_island_2l": (case_biharm, "private_mod.f95"),
+    "obc_mcbc0_yper_2l": (case_obc_yper, "private_mod.f95"),
     "jet_2l_xyper_dt3d": (lambda: _with_dt3d(I.case_unstable_jet(lm=21, mm=27, nlay=2, dt_s=1.5, dt_o=0.45)), "private_mod.f95"),
     "stommel_24x16_dt3d": (lambda: _with_dt3d(I.case_stommel(lm=24, mm=16, dl=100.0e3, dt_s=0.2), 2), "private_mod.f95"),
     "random_coast_2l_xper": (case_random_coast, "private_mod.f95"),

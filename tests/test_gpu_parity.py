@@ -259,6 +259,27 @@ def test_rigid_lid_larger_frames_match_oracle(case):
     fast.close(); tab.close()
 
 
+def test_rigid_lid_pipeline_of_sweeps_at_size():
+    """surf_pressure's Gauss-Seidel iteration as a pipeline of wavefronts (several sweeps in flight, one copy of the pressure
+    per sweep; beom_engine.hip lid_solve) on a frame of half a million cells, with a wind strong enough for dozens of sweeps
+    per step: lid pressure and state bit for bit against the oracle's serial sweeps, the count of sweeps kept included."""
+    from beom_amd import inputs as I
+    from beom_amd.grid import read_input_data
+    p, files = I.case_headline(1024, 512, 2)
+    p = p.replace(rgld="1.", ocrp="1.", g_fb="0.", bdrg="2.e-4", tauw=["0.5", "0.2"])
+    f = read_input_data(p, files=files)
+    e, o = capi.Engine(f), oracle_lib.Oracle(f)
+    assert e.info("lid_sweep_distance") == 2          # a plain frame: sweep s + 1 follows two levels behind sweep s
+    for t, n in ((1, 3), (4, 5)):
+        e.step(t, n); o.step(t, n)
+        assert same_bits(e.download_pressure(), o.rgld["pi_s"]), t
+        st = e.download()
+        for k in ("hlay", "u", "v", "h_u", "h_v"):
+            assert same_bits(st[k], o.state()[k]), (t, k)
+    assert e.info("lid_solves") == 8 and e.info("lid_sweeps") > 8
+    e.close()
+
+
 def test_restart_split_equals_single_run():
     """download → new handle → upload → continue == uninterrupted run (state incl. histories)."""
     g = Golden("sill_2l_ocrp")
@@ -564,6 +585,11 @@ def test_profile_start_stop_counts_launches():
     e.profile_start()
     e.step(5, 6, sync=False)
     ms, nl = e.profile_stop()
+    assert nl == [6, 6, 0, 0, 0, 0, 0, 6]    # H, Montgomery, Leith + u + v in one sweep (option "fold_leith")
+    e.set_option("fold_leith", 0)
+    e.profile_start()
+    e.step(11, 6, sync=False)
+    ms, nl = e.profile_stop()
     assert nl == [6, 0, 0, 0, 0, 6, 6, 0]    # fused pairs: H, mont+visc, u+v
     assert all(m > 0 for i, m in enumerate(ms) if nl[i])
     e.set_option("fuse", 0)
@@ -576,7 +602,7 @@ def test_profile_start_stop_counts_launches():
     e.profile_start()
     e.step(21, 10, sync=False)
     ms, nl = e.profile_stop()
-    assert nl == [2, 0, 0, 0, 0, 2, 2, 0]
+    assert nl == [2, 0, 0, 0, 0, 2, 2, 0]    # (the Leith fold is still off)
     e.close()
 
 
@@ -731,7 +757,8 @@ def test_device_side_output_records(name):
                                         ("beach_tall_noleith", 3), ("closed_tall_dt3d", 3),
                                         ("jet_xyper_tall", 2), ("jet_xyper_tall", 3), ("jet_yper_wind_tall", 2),
                                         ("jet_xyper_tall", 1), ("jet_xyper_tall_rccl", 1), ("closed_tall_rccl", 1),
-                                        ("sponge_obc_tall", 2), ("sponge_obc_tall", 3)])
+                                        ("sponge_obc_tall", 2), ("sponge_obc_tall", 3),
+                                        ("jet_yper_obc_tall", 1), ("jet_yper_obc_tall", 2), ("jet_yper_obc_tall", 3)])
 def test_one_process_several_bands_match_single_handle(case, nband):
     """beom_multi_* (the single-process multi-GPU form the Fortran host uses): bands of rows, ghost
     exchange by peer copy on second streams, overlapped split steps — here with every band on
@@ -741,7 +768,9 @@ def test_one_process_several_bands_match_single_handle(case, nband):
     carried by the companion frame; with ONE band the ring closes on itself — over peer copies, and
     (*_rccl) over RCCL with a one-rank communicator, the only RCCL form a one-GPU box can run.
     sponge_obc_tall: nudged open boundaries with mcbc = 0 — the segments of no_gradient_obc (:2613-2679) are dealt to the bands
-    (western and eastern boundaries cross every band; the southern and northern ones belong to the first and last)."""
+    (western and eastern boundaries cross every band; the southern and northern ones belong to the first and last).
+    jet_yper_obc_tall: the same on a frame periodic in y — a ring of bands whose companion frame gets the segments' ends in
+    rows 1..6, mm-3..mm and in the orphan row mm+1."""
     from beom_amd import inputs as I
     from beom_amd.grid import read_input_data
     rccl = case.endswith("_rccl")
@@ -750,7 +779,17 @@ def test_one_process_several_bands_match_single_handle(case, nband):
     def jet_wind():
         p, files = I.case_unstable_jet(lm=131, mm=151, nlay=2, dt_s=1.5)
         return p.replace(xper="0.", bdrg="2.e-4", tauw=["0.05", "0.02"]), files
+    def jet_obc():
+        p, files = I.case_unstable_jet(lm=131, mm=151, nlay=2, dt_s=1.5)
+        nudg = np.zeros((p.lm + 2, p.mm + 2, 3))
+        for i in range(0, 9):                                   # western sponge (eta, u), dry margin included
+            nudg[i, :, 0:2] = 0.3 * (9 - i) / 9.0
+        for i in range(p.lm + 1, p.lm - 7, -1):                 # eastern sponge
+            w = 0.25 * (i - (p.lm - 7)) / 9.0
+            nudg[i, :, 0] = np.maximum(nudg[i, :, 0], w); nudg[i, :, 1] = np.maximum(nudg[i, :, 1], w)
+        return p.replace(xper="0.", mcbc="0."), dict(files, nudg=nudg)
     p, files = {
+        "jet_yper_obc_tall": jet_obc,
         "jet_xyper_tall": lambda: I.case_unstable_jet(lm=131, mm=151, nlay=2, dt_s=1.5),
         "jet_yper_wind_tall": jet_wind,
         "closed_tall": lambda: I.case_headline(150, 260, 3),

@@ -65,6 +65,7 @@ def _run_host(g, work, ngpu=1):
                          + [("stommel_24x16", 2), ("sill_4l_ocrp", 3), ("tide_sponge", 2), ("variant3d_3l", 2),
                             ("jet_2l_xyper", 2), ("tc_conservation_xyper_stdfb", 3),      # periodic in y: a ring of bands
                             ("obc_mcbc0_2l", 2), ("obc_mcbc0_2l", 3),                       # open-boundary segments dealt to the bands
+                            ("obc_mcbc0_yper_2l", 2), ("obc_mcbc0_yper_2l", 3),             # ... of a ring of bands (+ the companion frame)
                             ("island_3l_forced", 2), ("tc_outcrop_seamount_3d_3l", 2), ("topdrag_topo_2l", 3)])   # land: bands of packed rows
 def test_fortran_host_reproduces_reference_output_files(name, ngpu):
     """ngpu > 1: the same program with BEOM_NGPU set — the library cuts the frame into row bands
