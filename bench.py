@@ -41,11 +41,10 @@ B_ALG_KERNEL = {              # per sweep, bytes per cell-layer (SURVEY §8d wor
     "update_h": 7 * 8, "update_mont": 9 * 8, "update_viscosity": 4 * 8, "update_u": 16 * 8, "update_v": 16 * 8,
     # fused launches do the work of two reference sweeps: their algorithmic bytes are the sum
     "update_mont+update_viscosity": (9 + 4) * 8, "update_u+update_v": (16 + 16) * 8,
-    # the Leith products formed inside the momentum sweep (option "fold_leith"): that launch does the work of three reference sweeps
-    "update_viscosity+update_u+update_v": (4 + 16 + 16) * 8,
+    "(unused)": 0,
 }
 KERNEL_ORDER = ("update_h", "update_mont", "update_viscosity", "update_u", "update_v",
-                "update_mont+update_viscosity", "update_u+update_v", "update_viscosity+update_u+update_v")
+                "update_mont+update_viscosity", "update_u+update_v", "(unused)")
 NCLS = len(KERNEL_ORDER)
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec (≈6.3 TB/s achievable)
 
@@ -79,7 +78,10 @@ def parse():
                          "uploaded again afterwards")
     ap.add_argument("--single-process", action="store_true",
                     help="N > 1: ONE process drives all N devices (beom_multi_create from global arrays)")
-    ap.add_argument("--transport", default="rccl", choices=("rccl", "peer"), help="--single-process only")
+    ap.add_argument("--transport", default="rccl", choices=("rccl", "peer", "shm"),
+                    help="rccl (default) | peer: --single-process only | shm: one rank per band as usual, the ghost rows staged "
+                         "through shared memory — a rehearsal of the N-rank run on a box with fewer GPUs than ranks (the ranks "
+                         "then share devices: LOCAL_RANK modulo the visible count); a result measured that way says so")
     ap.add_argument("--force-bands", action="store_true",
                     help="rehearsal on one GPU: take the N > 1 path (rows from the recipe, beom_multi_create_local, RCCL) "
                          "with a single band; with --case jet the ring then closes on itself over RCCL")
@@ -187,6 +189,9 @@ def main():
     import torch.distributed as dist
 
     ndev = max(torch.cuda.device_count(), 1)
+    shm = a.transport == "shm" and not a.single_process
+    if shm:
+        local_rank = local_rank % ndev
     if local_rank >= ndev:
         raise SystemExit("bench.py: LOCAL_RANK %d but only %d GPUs visible" % (local_rank, ndev))
     if a.single_process and a.gpus > ndev and a.transport == "rccl":
@@ -221,7 +226,10 @@ def main():
         why = None
         eng = None
         try:
-            uid = [capi.rccl_unique_id() if rank == 0 else None]
+            if shm:
+                uid = ["/beom_bench_%d_%s" % (os.getpid(), os.urandom(6).hex()) if rank == 0 else None]
+            else:
+                uid = [capi.rccl_unique_id() if rank == 0 else None]
         except capi.BeomError as exc:                                    # librccl could not be bound on this machine
             uid, why = [b""], str(exc)
         if world > 1:
@@ -229,7 +237,8 @@ def main():
         if uid[0]:
             try:
                 f, geom, orphan = slab.build_band(recipe, world, rank)   # this rank's rows only
-                eng = capi.BandEngine(f, p, world, rank, device=local_rank, rccl_id=uid[0], orphan=orphan)
+                eng = capi.BandEngine(f, p, world, rank, device=local_rank, orphan=orphan,
+                                      **(dict(shm_name=uid[0]) if shm else dict(rccl_id=uid[0])))
             except capi.BeomError as exc:
                 why = str(exc)
         ok = eng is not None
@@ -278,6 +287,9 @@ def main():
                 "fields": list(slab.EXCHANGED), "bytes_per_direction_per_step": len(slab.EXCHANGED) * p.nlay * slab.GHOST * L * 8,
                 "step_loop": "inside the library (beom_multi_step)", "state_build": "global arrays, cut by the library"
                 if a.single_process else "each rank builds its own rows from the recipe"}
+        if shm:
+            halo["rehearsal"] = ("ghost rows staged through shared memory, %d ranks on %d device(s): the N-rank code path, NOT an "
+                                 "N-GPU measurement" % (world, len({x["device"] for x in seen})))
         halo["per_kernel_note"] = ("a cut step launches the momentum sweep twice (the strips next to the ghost zones on the second stream, "
                                    "the rows in between on the main one, side by side): roofline.per_kernel sums both, so concurrent time "
                                    "is counted twice there; `value` is wall time")

@@ -56,8 +56,6 @@ struct DevView {
     int keep_diag;                // fused sweep also stores rvor, dive, v_cc, v_ll
     int keep_visc;                // fused sweep (Leith) also stores v_cc, v_ll: they stand for n_3d - 1 more steps
     int zero_visc;                // v_cc = v_ll = +0 everywhere and never refreshed: the viscous products are +-0
-    int prod_in_uv;               // Leith refreshed on every step: the interior workgroups of the fused u+v sweep form the
-                                  // products from the u, v they stage; k_mont_visc leaves Leith and pcd, qlr of deep tiles alone
     int lean_d2h;                 // fused sweep stores d2hx, d2hy only where the fused u+v sweep reads them
     int edge_global;              // k_uv_fused: edge workgroups read global memory throughout (A/B switch; default: staged by lookup)
     // biharmonic viscosity (svis > 0, :2508-2599): Laplacians and thickness-weighted fluxes

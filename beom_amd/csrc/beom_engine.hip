@@ -90,7 +90,6 @@ struct beom_engine {
     // distribute_stress inside the fused momentum sweep (option "fold_stress", default on): possible when the fractions are
     // constants (ocrp = 0) and nothing the sweep would have to read was uploaded into an array the engine does not refresh
     bool fold_stress = true, fold_static_ok = false;
-    bool fold_leith = true;            // option "fold_leith": the Leith products of deep tiles are formed inside the fused u+v sweep
     bool up_tt = false, up_tb = false, up_tu = false;   // a non-zero tt3d / tb3d / tu3d has been uploaded
     bool last_folded = false;          // the last step formed its stress inside the momentum sweep (beom_info "stress_folded")
     float *h0r4_dev = nullptr, *out4[3] = {nullptr, nullptr, nullptr};   // device-side output staging
@@ -451,8 +450,7 @@ int beom_create(const beom_params *prm, int device, const int32_t *neig, const i
     E->top = prm->tdrg > 1.e-7;                                                                                  // :1991
     d.has_wind = E->wind; d.has_bot = E->bot; d.has_top = E->top;
     d.has_stress = E->wind || E->bot || E->top;
-    d.stress_fold = 0; d.prod_in_uv = 0;
-    E->fold_leith = getenv("BEOM_NO_FOLD_LEITH") == nullptr;
+    d.stress_fold = 0;
     d.rho_top = prm->rhon[0]; d.rho_bot = prm->rhon[nl - 1];
     {
         bool neg0 = false;                         // a body force of exactly -0 would make the sign of a skipped +-0 visible
@@ -822,16 +820,11 @@ static void launch_uv(beom_engine *E, int ilay, double gene, double ramp, double
 // fused Montgomery + Leith sweep (dense frames); false if no instantiation for this nlay
 // leith: this step refreshes the Leith viscosity (:2188, :2268); else the sweep forms the products of the
 // standing v_cc, v_ll.  keep_visc: a refreshed viscosity has to stand for later steps (n_3d > 1).
-// the Leith products of deep tiles are formed inside the fused u+v sweep (k_uv_fused<.., LF>) instead of k_mont_visc
-static bool leith_folds(const beom_engine *E, bool uv_fused_follows, bool leith, bool keep_visc) {
-    return leith && uv_fused_follows && E->fold_leith && !keep_visc && !E->d.keep_diag;
-}
 static bool launch_mont_visc(beom_engine *E, bool uv_fused_follows, bool leith, bool keep_visc) {
     E->d.lean_d2h = uv_fused_follows && E->lean_d2h && !E->d.keep_diag;
     E->d.keep_visc = keep_visc;
     E->d.zero_visc = !leith && uv_fused_follows && E->lean_visc && E->visc_all_zero && E->P.dvis == 0.0 && E->P.bvis == 0.0 &&
                      !E->d.keep_diag;
-    E->d.prod_in_uv = leith_folds(E, uv_fused_follows, leith, keep_visc);
     return E->tile4 ? raw_mont_visc_t4(E, leith) : raw_mont_visc_t8(E, leith);
 }
 // fused U+V sweep (dense frames): first_x = update_u first (even tstp)
@@ -979,10 +972,7 @@ static void one_step(beom_engine *E, int tstp, const StepScalars &s) {
     if (E->lid) launch_lid_h_epilogue(E);                          // :1648-1700
     const bool leith = E->P.dvis > 1.e-3 && s.upst;
     const bool u_first = tstp % 2 == 0;                            // :2193-2199,2276-2282
-    // timer classes: with the Leith products formed in the u+v sweep, the Montgomery launch counts as update_mont (1) and the
-    // momentum launch as update_viscosity + update_u + update_v (7)
-    const bool lf = s.fused && leith_folds(E, s.fused_uv, leith, leith && s.n_3d > 1);
-    if (T) { T->end(); T->begin(s.fused && !lf ? 5 : 1); }
+    if (T) { T->end(); T->begin(s.fused ? 5 : 1); }
     const bool prod = s.fused && launch_mont_visc(E, s.fused_uv, leith, leith && s.n_3d > 1);              // :2187-2188, 2266-2269 in one sweep
     if (!prod) launch_mont(E, 0);
     if (T) T->end();
@@ -992,7 +982,7 @@ static void one_step(beom_engine *E, int tstp, const StepScalars &s) {
         if (T) T->end();
     }
     if (s.fused_uv) {
-        if (T) T->begin(lf && prod ? 7 : 6);
+        if (T) T->begin(6);
         launch_uv_fused(E, u_first, prod, s.gene, s.ramp, s.ctim);
         if (T) T->end();
     } else if (u_first) {
@@ -1124,7 +1114,7 @@ int beom_step_phase(beom_handle E, int tstp, double tres, double dtd8, double dt
         if (T) T->begin(0);
         launch_h(E, s.gene, s.ramp, s.ctim);                           // :2181,2259
         const bool leith = E->P.dvis > 1.e-3 && s.upst;
-        if (T) { T->end(); T->begin(s.fused && !leith_folds(E, true, leith, leith && s.n_3d > 1) ? 5 : 1); }
+        if (T) { T->end(); T->begin(s.fused ? 5 : 1); }
         E->split_prod = s.fused && launch_mont_visc(E, true, leith, leith && s.n_3d > 1);
         if (!E->split_prod) launch_mont(E, 0);
         if (T) T->end();
@@ -1138,12 +1128,12 @@ int beom_step_phase(beom_handle E, int tstp, double tres, double dtd8, double dt
         if (south && north) set_rows(d, 2, 1, kEdgeRows, M - kEdgeRows + 1, M);
         else if (south) set_rows(d, 1, 1, kEdgeRows);
         else set_rows(d, 1, M - kEdgeRows + 1, M);
-        if (T) T->begin(E->split_prod && d.prod_in_uv ? 7 : 6);
+        if (T) T->begin(6);
         launch_uv_fused(E, u_first, E->split_prod, s.gene, s.ramp, s.ctim, false);
         if (T) T->end();
     } else {
         set_rows(d, 1, south ? kEdgeRows + 1 : 1, north ? M - kEdgeRows : M);
-        if (T) T->begin(E->split_prod && d.prod_in_uv ? 7 : 6);
+        if (T) T->begin(6);
         launch_uv_fused(E, u_first, E->split_prod, s.gene, s.ramp, s.ctim, true);
         if (T) T->end();
     }
@@ -1310,7 +1300,6 @@ int beom_set_option(beom_handle E, const char *name, int value) {
     else if (!strcmp(name, "fuse_uv")) E->fuse_uv = value != 0 && !E->lid;
     else if (!strcmp(name, "keep_diag")) E->d.keep_diag = value != 0;
     else if (!strcmp(name, "fold_stress")) E->fold_stress = value != 0;
-    else if (!strcmp(name, "fold_leith")) E->fold_leith = value != 0;
     else if (!strcmp(name, "profile_stride")) E->profile_stride = value > 0 ? value : 1;
     else if (!strcmp(name, "profile_rotate")) E->profile_rotate = value != 0;
     else if (!strcmp(name, "lean_d2h")) E->lean_d2h = value != 0;

@@ -384,9 +384,8 @@ __device__ __forceinline__ void body_mont_visc(const DevView &d, int x0, int y0,
             if (INT || ok[q]) uv6_load<INT>(d, c[q], ilay, w[q]);
             else { w[q][0] = w[q][1] = w[q][2] = w[q][3] = w[q][4] = w[q][5] = 0.0; }
             if (!LEITH) {     // zero_visc: v_cc = v_ll = +0 everywhere (dvis = bvis = 0), verified by the engine
-                // (!wr_prod: nobody reads this tile's products — zero viscosity, or the momentum sweep forms them itself)
-                vcc0[q] = (d.zero_visc || !wr_prod) ? 0.0 : LL(d.v_cc, c[q].ipnt, ilay);
-                vll0[q] = (d.zero_visc || !wr_prod) ? 0.0 : LL(d.v_ll, c[q].ipnt, ilay);
+                vcc0[q] = d.zero_visc ? 0.0 : LL(d.v_cc, c[q].ipnt, ilay);
+                vll0[q] = d.zero_visc ? 0.0 : LL(d.v_ll, c[q].ipnt, ilay);
             }
         }
         if (hr >= 0) {
@@ -535,11 +534,8 @@ __global__ __launch_bounds__(BEOM_BLOCK) MV_OCC_ATTR void k_mont_visc(DevView d)
         for (int dy = -1; dy <= 1; ++dy)
             for (int dx = -1; dx <= 1; ++dx) deep = deep && tile_regular(d, x0 + dx * UV_TX, uy0 + dy * UV_TY, UV_TY);
     const bool wr_d2h = !(d.lean_d2h && deep);
-    // zero viscosity: interior workgroups of k_uv_fused skip the term; prod_in_uv: they form the Leith products themselves
-    // from the u, v they stage (k_uv_fused<.., LF>), so a deep tile neither evaluates Leith nor stores pcd, qlr
-    const bool wr_prod = !((d.zero_visc || d.prod_in_uv) && deep);
-    if (LEITH && !wr_prod) body_mont_visc<NL, true, false>(d, x0, y0, wr_d2h, false, nullptr, nullptr, s_hh);
-    else if (interior) body_mont_visc<NL, true, LEITH>(d, x0, y0, wr_d2h, wr_prod, (double (*)[MV_LDY][MV_LDX])s_rv, (double (*)[MV_LDY][MV_LDX])s_dv, s_hh);
+    const bool wr_prod = !(d.zero_visc && deep);   // zero viscosity: interior workgroups of k_uv_fused skip the term
+    if (interior) body_mont_visc<NL, true, LEITH>(d, x0, y0, wr_d2h, wr_prod, (double (*)[MV_LDY][MV_LDX])s_rv, (double (*)[MV_LDY][MV_LDX])s_dv, s_hh);
     else body_mont_visc<NL, false, LEITH>(d, x0, y0, wr_d2h, wr_prod, (double (*)[MV_LDY][MV_LDX])s_rv, (double (*)[MV_LDY][MV_LDX])s_dv, s_hh);
 }
 static inline dim3 mont_visc_grid(const DevView &d) { return dim3(TileMap(d, MV_TX, MV_TY).blocks(), 1, 1); }
@@ -895,22 +891,10 @@ __device__ __forceinline__ void uv_pre_load(const DevView &d, const CellDenseT<t
     if (gene != 0.0) { pre[5] = LL(dm[0], ipnt, ilay); pre[6] = LL(dm[1], ipnt, ilay); pre[7] = LL(dm[2], ipnt, ilay); }
 }
 
-// LF (Leith folded, DevView::prod_in_uv): the viscous products pcd = v_cc*dive, qlr = v_ll*rvor of tile + ring are not
-// loaded but FORMED here — u, v of tile + 3 cells are staged, rvor and dive (:2388-2389, :2435-2436; masks 1 in the wet
-// interior) evaluated on tile + 2 into the same LDS memory, the Leith viscosities (:2458-2502) and their products on tile +
-// 1 straight into the stage slots the momentum updates read.  Same operations in the same order as k_mont_visc, which then
-// neither evaluates Leith nor stores the two arrays for such tiles: 4 words per cell-layer less through HBM.
-#define UV_UROWS (UV_TY + 6)
-#define UV_UCOLS (UV_TX + 6)
-#define UV_RROWS (UV_TY + 4)
-#define UV_RCOLS (UV_TX + 4)
-#define UV_RLDX (UV_RCOLS + 1)
-static_assert(2 * UV_RROWS * UV_RLDX <= 2 * UV_UROWS * UV_UCOLS, "rvor/dive overlay the staged velocities");
-
-template <bool FIRST_X, bool ZV, bool LF = false>
+template <bool FIRST_X, bool ZV>
 __device__ __forceinline__ void body_uv_fused_staged(const DevView &d, int x0, int y0, int ilay, double gene,
                                                      double ramp, double ctim, double (*s_h)[UV_LDX], UVstage *s_f,
-                                                     double (*s_hl)[UV_HLDX], double *s_uv = nullptr) {
+                                                     double (*s_hl)[UV_HLDX]) {
     const int tid = threadIdx.x;
     const int lx = tid & 63, wy = tid >> 6;
     const int i = x0 + lx;
@@ -918,37 +902,9 @@ __device__ __forceinline__ void body_uv_fused_staged(const DevView &d, int x0, i
     constexpr int NST = UV_SROWS * (UV_TX + 2), NIT = (NST + UV_BLOCK - 1) / UV_BLOCK;
     const long long lay = d.n1 * (long long)(ilay - 1);
     // ---- phase A loads: stage elements, outer hlay ring, first update of own cells and of the ring cell
-    // ZV (zero viscosity): pcd, qlr are neither staged nor read; LF: they are formed below, not loaded
-    constexpr int NF = (ZV || LF) ? 2 : 4;
-    const double *src[5] = {d.mont, d.pvor, (ZV || LF) ? d.hlay : d.pcd, (ZV || LF) ? d.hlay : d.qlr, d.hlay};
-#ifndef UV_LF_DIRECT
-#define UV_LF_DIRECT 0      // 0: u, v of tile + 3 staged in LDS first; 1: rvor, dive of tile + 2 straight from global u, v (6 loads
-                            //    per point, issued with the other loads of the phase: two barriers less, 24 more VGPRs)
-#endif
-    constexpr int NUV = (LF && !UV_LF_DIRECT) ? UV_UROWS * UV_UCOLS : 1, NITU = (NUV + UV_BLOCK - 1) / UV_BLOCK;
-    double uu[NITU], vv[NITU];
-    constexpr int NRV = LF ? UV_RROWS * UV_RCOLS : 1, NITR = (NRV + UV_BLOCK - 1) / UV_BLOCK;
-    double w6[NITR][6];
-    if (LF && UV_LF_DIRECT) {
-#pragma unroll
-        for (int k = 0; k < NITR; ++k) {
-            const int idx = tid + k * UV_BLOCK;
-            const int idc = idx < NRV ? idx : tid;
-            const int r2 = idc / UV_RCOLS, c2 = idc - r2 * UV_RCOLS;
-            const long long ip = (long long)(x0 - 2 + c2) + (long long)(y0 - 3 + r2) * d.P + lay;     // cell (x0-2+c2, y0-2+r2)
-            w6[k][0] = d.u[ip]; w6[k][1] = d.u[ip + 1]; w6[k][2] = d.v[ip]; w6[k][3] = d.v[ip + d.P];     // u, u(E), v, v(N)
-            w6[k][4] = d.v[ip - 1]; w6[k][5] = d.u[ip - d.P];                                             // v(W), u(S)
-        }
-    } else if (LF) {
-#pragma unroll
-        for (int k = 0; k < NITU; ++k) {
-            const int idx = tid + k * UV_BLOCK;
-            const int idc = idx < NUV ? idx : tid;
-            const int rr = idc / UV_UCOLS, cc = idc - rr * UV_UCOLS;
-            const long long ip = (long long)(x0 - 3 + cc) + (long long)(y0 - 4 + rr) * d.P + lay;
-            uu[k] = d.u[ip]; vv[k] = d.v[ip];
-        }
-    }
+    // ZV (zero viscosity): pcd, qlr are neither staged nor read
+    constexpr int NF = ZV ? 2 : 4;
+    const double *src[5] = {d.mont, d.pvor, ZV ? d.hlay : d.pcd, ZV ? d.hlay : d.qlr, d.hlay};
     double fv[NIT][5];
     int frr[NIT], fcc[NIT];
 #pragma unroll
@@ -998,71 +954,6 @@ __device__ __forceinline__ void body_uv_fused_staged(const DevView &d, int x0, i
         }
     }
     if (hrr >= 0) s_hl[hrr][hcc] = hring;
-    if (LF) {
-        double rvv[NITR], dvv[NITR];
-        if (UV_LF_DIRECT) {
-            // rvor, dive of the cells (x0-2+c2, y0-2+r2): update_mont's expressions with mkpe = 1 (rv_dv_calc)
-#pragma unroll
-            for (int k = 0; k < NITR; ++k) {
-                rvv[k] = (w6[k][2] - w6[k][4] - w6[k][0] + w6[k][5]) * d.i_dl * 1.0;
-                dvv[k] = (w6[k][1] - w6[k][0] + w6[k][3] - w6[k][2]) * d.i_dl;
-            }
-        } else {
-            double (*su)[UV_UCOLS] = (double (*)[UV_UCOLS])s_uv, (*sv)[UV_UCOLS] = su + UV_UROWS;
-#pragma unroll
-            for (int k = 0; k < NITU; ++k) {
-                const int idx = tid + k * UV_BLOCK;
-                if (idx < NUV) { const int rr = idx / UV_UCOLS, cc = idx - rr * UV_UCOLS; su[rr][cc] = uu[k]; sv[rr][cc] = vv[k]; }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < NITR; ++k) {
-                const int idx = tid + k * UV_BLOCK;
-                const int idc = idx < NRV ? idx : tid;
-                const int r2 = idc / UV_RCOLS, c2 = idc - r2 * UV_RCOLS;
-                const double u0 = su[r2 + 1][c2 + 1], v0 = sv[r2 + 1][c2 + 1];
-                rvv[k] = (v0 - sv[r2 + 1][c2] - u0 + su[r2][c2 + 1]) * d.i_dl * 1.0;
-                dvv[k] = (su[r2 + 1][c2 + 2] - u0 + sv[r2 + 2][c2 + 1] - v0) * d.i_dl;
-            }
-            __syncthreads();                              // every thread has read the velocities it needs
-        }
-        double (*srv)[UV_RLDX] = (double (*)[UV_RLDX])s_uv, (*sdv)[UV_RLDX] = srv + UV_RROWS;
-#pragma unroll
-        for (int k = 0; k < NITR; ++k) {
-            const int idx = tid + k * UV_BLOCK;
-            if (idx < NRV) { const int r2 = idx / UV_RCOLS, c2 = idx - r2 * UV_RCOLS; srv[r2][c2] = rvv[k]; sdv[r2][c2] = dvv[k]; }
-        }
-        __syncthreads();
-        // the products at the stage positions (x0-1+c1, y0-1+r1); names as in update_viscosity (:2458-2470).  Into registers
-        // first: their stage slots share LDS memory with rvor / dive (k_uv_fused)
-        double pcdv[NIT], qlrv[NIT];
-#pragma unroll
-        for (int k = 0; k < NIT; ++k) {
-            pcdv[k] = 0.0; qlrv[k] = 0.0;
-            if (tid + k * UV_BLOCK >= NST) continue;
-            const int r = frr[k] + 1, cx = fcc[k] + 1;
-            const double r_bl = srv[r][cx], r_br = srv[r][cx + 1], r_tr = srv[r + 1][cx + 1], r_tl = srv[r + 1][cx],
-                         rbll = srv[r][cx - 1], rbbl = srv[r - 1][cx];
-            const double d_cc = sdv[r][cx], d_ri = sdv[r][cx + 1], d_to = sdv[r + 1][cx], d_le = sdv[r][cx - 1],
-                         d_bl = sdv[r - 1][cx - 1], d_bo = sdv[r - 1][cx];
-            const double a = (r_br - r_bl) * (r_br - r_bl) + (r_bl - rbll) * (r_bl - rbll)
-                           + (r_tl - r_bl) * (r_tl - r_bl) + (r_bl - rbbl) * (r_bl - rbbl)
-                           + (d_cc - d_le) * (d_cc - d_le) + (d_bo - d_bl) * (d_bo - d_bl)
-                           + (d_cc - d_bo) * (d_cc - d_bo) + (d_le - d_bl) * (d_le - d_bl);
-            const double vll = sqrt(a) * d.dvis * d.dl * d.dl + d.bvis;
-            const double b = (r_br - r_bl) * (r_br - r_bl) + (r_tr - r_tl) * (r_tr - r_tl)
-                           + (r_tl - r_bl) * (r_tl - r_bl) + (r_tr - r_br) * (r_tr - r_br)
-                           + (d_ri - d_cc) * (d_ri - d_cc) + (d_cc - d_le) * (d_cc - d_le)
-                           + (d_to - d_cc) * (d_to - d_cc) + (d_cc - d_bo) * (d_cc - d_bo);
-            const double vcc = sqrt(b) * d.dvis * d.dl * d.dl + d.bvis;
-            pcdv[k] = vcc * d_cc;
-            qlrv[k] = vll * r_bl;
-        }
-        __syncthreads();                                  // every thread has read the rvor, dive it needs
-#pragma unroll
-        for (int k = 0; k < NIT; ++k)
-            if (tid + k * UV_BLOCK < NST) { s_f[2][frr[k]][fcc[k]] = pcdv[k]; s_f[3][frr[k]][fcc[k]] = qlrv[k]; }
-    }
     __syncthreads();
     // ---- phase B loads (second update): in flight while the first update is evaluated
     double pre2[UV_Q][8];
@@ -1318,33 +1209,11 @@ __device__ __forceinline__ void body_uv_fused_edge(const DevView &d, int x0, int
 #else
 #define UV_OCC_ATTR
 #endif
-// LDS of one workgroup: [mont | pvor | pcd | qlr] stages, the first update's transports, the wider hlay stage.  LF: the
-// staged velocities (tile + 3), later rvor / dive (tile + 2), live in the memory of pcd | qlr | transports, which are
-// written only after them — the fold costs no LDS, so four workgroups still fit a CU (three cost the sweep 9 %: measured
-// with 14 KB of unused LDS, profiles/r03_leith_fold.txt).
-#define UV_STAGE_N (UV_SROWS * UV_SLDX)
-#define UV_SH_N ((UV_TY + 1) * UV_LDX)
-#define UV_OV_N (UV_LF_DIRECT ? 2 * UV_RROWS * UV_RLDX : 2 * UV_UROWS * UV_UCOLS)
-#define UV_BUF_N ((2 * UV_STAGE_N + UV_OV_N) > (4 * UV_STAGE_N + UV_SH_N) ? (2 * UV_STAGE_N + UV_OV_N) : (4 * UV_STAGE_N + UV_SH_N))
-#ifndef UV_LF_WAVES_PER_EU
-#define UV_LF_WAVES_PER_EU 4          // the folded form would take 134 VGPRs (three waves per SIMD) left alone
-#endif
-#if UV_LF_WAVES_PER_EU > 0
-#define UV_LF_OCC_ATTR __attribute__((amdgpu_waves_per_eu(UV_LF_WAVES_PER_EU)))
-#else
-#define UV_LF_OCC_ATTR
-#endif
-template <bool FIRST_X, bool PROD, bool ZV, bool LF>
-__device__ __forceinline__ void uv_fused_kernel_body(const DevView &d, double gene, double ramp, double ctim) {
-    __shared__ double s_buf[PROD ? UV_BUF_N : UV_SH_N + UV_STAGE_N];
+template <bool FIRST_X, bool PROD, bool ZV = false>
+__global__ __launch_bounds__(UV_BLOCK) UV_OCC_ATTR void k_uv_fused(DevView d, double gene, double ramp, double ctim) {
+    __shared__ double s_h[UV_TY + 1][UV_LDX];
+    __shared__ UVstage s_f[PROD ? 4 : 1];                    // (ZV: the interior workgroups use two of them, the edge ones all four)
     __shared__ double s_hl[PROD ? UV_HROWS : 1][UV_HLDX];
-    UVstage *s_f = (UVstage *)s_buf;                        // (ZV: the interior workgroups use two of them, the edge ones all four)
-    double (*s_h)[UV_LDX] = (double (*)[UV_LDX])(s_buf + (PROD ? 4 : 1) * UV_STAGE_N);
-    double *s_uv = s_buf + 2 * UV_STAGE_N;                   // LF: (u, v of tile + 3, then) rvor, dive of tile + 2
-#ifdef UV_PAD_LDS        // (experiment: what the occupancy of three workgroups per CU alone costs the sweep)
-    __shared__ double s_pad[UV_PAD_LDS / 8];
-    if (gene == -12345.0) s_pad[threadIdx.x] = ramp;
-#endif
     const TileMap tm(d, UV_TX, UV_TY);
     int ty, ch;
     if (!tm.locate(blockIdx.x, ty, ch)) return;
@@ -1352,19 +1221,10 @@ __device__ __forceinline__ void uv_fused_kernel_body(const DevView &d, double ge
     const int ilay = blockIdx.y + 1;
     const bool interior = x0 - 1 >= 2 && x0 + UV_TX <= d.L - 2 && y0 - 1 >= 2 && y0 + UV_TY <= d.M - 2
                           && y0 - 1 + d.joff >= 2 && y0 + UV_TY + d.joff <= d.Mg - 2 && tile_regular(d, x0, y0, UV_TY);
-    if (interior && PROD) body_uv_fused_staged<FIRST_X, ZV, LF>(d, x0, y0, ilay, gene, ramp, ctim, s_h, s_f, s_hl, s_uv);
+    if (interior && PROD) body_uv_fused_staged<FIRST_X, ZV>(d, x0, y0, ilay, gene, ramp, ctim, s_h, s_f, s_hl);
     else if (interior) body_uv_fused<FIRST_X, PROD, true>(d, x0, y0, ilay, gene, ramp, ctim, s_h);
     else if (PROD && !d.edge_global) body_uv_fused_edge<FIRST_X>(d, x0, y0, ilay, gene, ramp, ctim, s_h, s_f, s_hl);
     else body_uv_fused<FIRST_X, PROD, false>(d, x0, y0, ilay, gene, ramp, ctim, s_h);
-}
-template <bool FIRST_X, bool PROD, bool ZV = false>
-__global__ __launch_bounds__(UV_BLOCK) UV_OCC_ATTR void k_uv_fused(DevView d, double gene, double ramp, double ctim) {
-    uv_fused_kernel_body<FIRST_X, PROD, ZV, false>(d, gene, ramp, ctim);
-}
-// ... with the Leith products of interior tiles formed inside (option "fold_leith")
-template <bool FIRST_X>
-__global__ __launch_bounds__(UV_BLOCK) UV_LF_OCC_ATTR void k_uv_fused_lf(DevView d, double gene, double ramp, double ctim) {
-    uv_fused_kernel_body<FIRST_X, true, false, true>(d, gene, ramp, ctim);
 }
 static inline dim3 uv_fused_grid(const DevView &d) {
     return dim3(TileMap(d, UV_TX, UV_TY).blocks(), (unsigned)d.nlay, 1);

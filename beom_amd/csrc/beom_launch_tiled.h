@@ -19,11 +19,6 @@ static bool TFN(raw_mont_visc)(beom_engine *E, bool leith) {
 static void TFN(raw_uv_fused)(beom_engine *E, bool first_x, bool prod, bool zv, double gene, double ramp, double ctim) {
     const dim3 g = TNS::uv_fused_grid(E->d), b(TNS::kUvBlock);
     DevView &d = E->d;
-    if (prod && !zv && d.prod_in_uv) {            // the Leith products are formed inside the sweep
-        if (first_x) hipLaunchKernelGGL((TNS::k_uv_fused_lf<true>), g, b, 0, E->stream, d, gene, ramp, ctim);
-        else hipLaunchKernelGGL((TNS::k_uv_fused_lf<false>), g, b, 0, E->stream, d, gene, ramp, ctim);
-        return;
-    }
     if (first_x) {
         if (zv) hipLaunchKernelGGL((TNS::k_uv_fused<true, true, true>), g, b, 0, E->stream, d, gene, ramp, ctim);
         else if (prod) hipLaunchKernelGGL((TNS::k_uv_fused<true, true>), g, b, 0, E->stream, d, gene, ramp, ctim);

@@ -211,9 +211,6 @@ int beom_unpack_rows2(beom_handle h, int nrows, int jlo_a, const void *buffer_a,
  *  "profile_rotate" (default 0): a sampled step brackets only ONE kind of sweep — update_h | update_mont, update_viscosity |
  *      update_u, update_v — by turns ((tstp / stride) % 3 = 0 | 1 | 2), so that no bracketed launch starts behind another
  *      bracket's bubble; the launch counts are then those of the steps that bracketed that kind.
- *  "fold_leith" (default 1): with the Leith viscosity refreshed on every step and the fused u+v sweep, the interior workgroups
- *      of that sweep form the products v_cc*dive, v_ll*rvor themselves (rvor, dive on tile + 2 from u, v; Leith on tile + 1)
- *      and the Montgomery sweep neither evaluates Leith nor stores the two product arrays away from the frame's edge.
  *  "fold_stress" (default 1): with constant layer fractions (ocrp = 0) and a stress refresh on every step (n_3d = 1), steps
  *      after the third form distribute_stress (private_mod.f95:1921-2149) inside the fused update_u/update_v sweep: no
  *      launch of its own, tt3d/tb3d/tu3d neither written nor read (they keep their values of step 1 unless "keep_diag" = 1).
@@ -251,9 +248,8 @@ int beom_is_dense(beom_handle h);
 /* Per-kernel device time, measured with HIP events on the handle's stream around every
  * sweep launched by beom_step between start and stop (no host synchronisation in
  * between): ms[0..7] = update_h, update_mont, update_viscosity, update_u, update_v,
- * fused mont+viscosity, fused u+v, fused viscosity+u+v (sums over launches; the last one when the Leith
- * products are formed inside the momentum sweep, option "fold_leith": the Montgomery launch then counts as
- * update_mont), launches[0..7] = number of launches in each class.  Both arrays need 8 entries. */
+ * fused mont+viscosity, fused u+v, (unused) (sums over launches), launches[0..7] = number of
+ * launches in each class.  Both arrays need 8 entries. */
 int beom_profile_start(beom_handle h);
 int beom_profile_stop(beom_handle h, double *ms, int *launches, char *errm, int errm_len);
 /* = beom_profile_start; beom_step(...); beom_profile_stop. */

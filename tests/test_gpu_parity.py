@@ -419,44 +419,6 @@ def test_dense_interior_waves_match_oracle_and_gather(case):
         e.close()
 
 
-@pytest.mark.parametrize("tile_rows", [4, 8])
-@pytest.mark.parametrize("case", ["closed_3l", "jet_xyper_2l", "sill_leith_3l"])
-def test_leith_products_formed_in_momentum_sweep(case, tile_rows):
-    """Option "fold_leith" (default on): with the Leith viscosity refreshed on every step, the interior workgroups of the
-    fused u+v sweep form v_cc*dive and v_ll*rvor themselves from the u, v they stage (k_uv_fused<.., LF>) and k_mont_visc
-    neither evaluates Leith nor stores the two arrays for deep tiles.  Both tile geometries, against the oracle and against
-    the same engine with the fold off, bit for bit with the sign of zero."""
-    import os
-    from beom_amd import inputs as I
-    from beom_amd.grid import read_input_data
-    if case == "closed_3l":
-        p, files = I.case_headline(330, 75, 3)
-    elif case == "jet_xyper_2l":
-        p, files = I.case_unstable_jet(lm=331, mm=151, nlay=2, dt_s=1.5)
-    else:
-        p, files = I.case_sill_exchange3d(lm=330, mm=141, nlay=3, dt_s=0.01, npts=5, sill_halfwidth=20.0)
-    f = read_input_data(p, files=files)
-    old = os.environ.get("BEOM_TILE4")
-    os.environ["BEOM_TILE4"] = "1" if tile_rows == 4 else "0"          # (read when a handle is created)
-    try:
-        fold, plain = capi.Engine(f), capi.Engine(f)
-    finally:
-        if old is None: os.environ.pop("BEOM_TILE4")
-        else: os.environ["BEOM_TILE4"] = old
-    assert fold.info("tile_rows") == tile_rows
-    plain.set_option("fold_leith", 0)
-    o = oracle_lib.Oracle(f)
-    for x in (fold, plain, o):
-        x.step(1, 7); x.step(8, 8)
-    a, b = fold.download(), plain.download()
-    for k in ("hlay", "u", "v", "h_u", "h_v", "rs_h", "dmdx", "dmdy"):
-        assert same_bits(a[k], o.state()[k]), (case, k, "folded vs oracle", maxrel(a[k], o.state()[k]))
-        assert same_bits(b[k], o.state()[k]), (case, k, "not folded vs oracle")
-    sa, sb = fold.download_scratch(), plain.download_scratch()
-    assert same(sa["mont"], sb["mont"]) and same(sa["pvor"], sb["pvor"])
-    fold.close(); plain.close()
-
-
 def _forced_cases():
     """Dense frames with constant layer fractions (ocrp = 0) and a stress refresh on every step (dt3d = 0): the engine forms
     distribute_stress inside its fused momentum sweep from step 4 on."""
@@ -585,11 +547,6 @@ def test_profile_start_stop_counts_launches():
     e.profile_start()
     e.step(5, 6, sync=False)
     ms, nl = e.profile_stop()
-    assert nl == [6, 6, 0, 0, 0, 0, 0, 6]    # H, Montgomery, Leith + u + v in one sweep (option "fold_leith")
-    e.set_option("fold_leith", 0)
-    e.profile_start()
-    e.step(11, 6, sync=False)
-    ms, nl = e.profile_stop()
     assert nl == [6, 0, 0, 0, 0, 6, 6, 0]    # fused pairs: H, mont+visc, u+v
     assert all(m > 0 for i, m in enumerate(ms) if nl[i])
     e.set_option("fuse", 0)
@@ -602,7 +559,7 @@ def test_profile_start_stop_counts_launches():
     e.profile_start()
     e.step(21, 10, sync=False)
     ms, nl = e.profile_stop()
-    assert nl == [2, 0, 0, 0, 0, 2, 2, 0]    # (the Leith fold is still off)
+    assert nl == [2, 0, 0, 0, 0, 2, 2, 0]
     e.close()
 
 

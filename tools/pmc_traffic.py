@@ -34,18 +34,10 @@ def classify(name):
 def load(d, counter):
     f = glob.glob(d + "/**/*_counter_collection.csv", recursive=True)[0]
     agg = collections.defaultdict(list)
-    rows = list(csv.DictReader(open(f)))
-    # option "fold_leith": k_uv_fused_lf forms the Leith products itself; the Montgomery launches of such a run count as
-    # update_mont and the momentum launches as update_viscosity + update_u + update_v (bench.py's classes)
-    lf = any("k_uv_fused_lf" in r["Kernel_Name"] for r in rows)
-    for r in rows:
+    for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter:
             continue
         c = classify(r["Kernel_Name"])
-        if lf and c == "update_mont+update_viscosity":
-            c = "update_mont"
-        if "k_uv_fused_lf" in r["Kernel_Name"]:
-            c = "update_viscosity+update_u+update_v"
         if c:
             agg[c].append(float(r["Counter_Value"]))
     return {k: sum(v[len(v) // 2:]) / len(v[len(v) // 2:]) for k, v in agg.items()}
