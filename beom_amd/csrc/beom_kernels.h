@@ -661,7 +661,8 @@ __device__ __forceinline__ double fold_drag(const C &c, const DevView &d, int il
     return tau * 0.5 * (1.0 + 1.0);
 }
 
-template <bool XDIR, bool PROD, bool STORE, class C, class SH>
+// SF (stress fold): distribute_stress formed here (a template switch: the unforced sweeps must not carry its registers)
+template <bool XDIR, bool PROD, bool STORE, bool SF, class C, class SH>
 __device__ __forceinline__ double uv_core(const C &c, const DevView &d, int ilay, double gene, double ramp,
                                           double ctim, int copy_hist, const UVio &io,
                                           double q0, double qb, double qa, double qd, const SH &sh,
@@ -690,7 +691,7 @@ __device__ __forceinline__ double uv_core(const C &c, const DevView &d, int ilay
     double rhsi = dmd4 * (1.0 - gene);
     if (XDIR) rhsi = rhsi + 0.25 * pv0 * (q0 + qb) + 0.25 * pva * (qa + qd);
     else      rhsi = rhsi - 0.25 * pv0 * (q0 + qb) - 0.25 * pva * (qa + qd);
-    if (d.stress_fold) {
+    if (SF) {
         // distribute_stress (:1921-2149) inside the sweep — ocrp = 0, a refresh on every step: the fractions are 1 in the top
         // layer (wind :1953, top drag :1999) resp. the bottom layer (:1977) and 0 elsewhere, so tt3d = taus there, tb3d / tu3d =
         // the drag at this point from the (old) velocities of that layer, by the reference's own operations.  In every other
@@ -764,7 +765,7 @@ __device__ __forceinline__ double uv_core(const C &c, const DevView &d, int ilay
     if (f_ng != 0.0 || vold == 0.0) {
         const double i__hh = 1.0 / (hcen + 1.0 - mask);
         double vfor = FNUD_(ipnt, ilay, IV);
-        if (d.stress_fold) {                   // tt3d = taus * fraction (1 in the top layer, 0 below), formed here (see above)
+        if (SF) {                              // tt3d = taus * fraction (1 in the top layer, 0 below), formed here (see above)
             const double lt = ilay == 1 ? 1.0 : 0.0;
             const double t0 = d.has_wind ? d.taus_cells[ipnt + d.n1 * (IO - 1)] * lt : 0.0, tb_ = d.has_wind ? d.taus_cells[cb + d.n1 * (IO - 1)] * lt : 0.0;
             const double ek = 0.5 * (t0 + tb_) * i_r1 * d.invf * i__hh * ramp;
@@ -809,7 +810,7 @@ __device__ __forceinline__ void body_update_uv(const C &c, const DevView &d, int
     double *const *dm = XDIR ? d.dmx : d.dmy;
     const UVio io{XDIR ? d.u : d.v, XDIR ? d.u : d.v, XDIR ? d.h_u : d.h_v, dm[0], dm[1], dm[2], dm[0]};
     const ShGlobal sh{d, ipnt, cb, ca, ilay};
-    uv_core<XDIR, PROD, true>(c, d, ilay, gene, ramp, ctim, copy_hist, io,
+    uv_core<XDIR, PROD, true, false>(c, d, ilay, gene, ramp, ctim, copy_hist, io,
                               LL(hq, ipnt, ilay), LL(hq, cb, ilay), LL(hq, ca, ilay), LL(hq, cd, ilay), sh);
 }
 template <class CTX, bool XDIR, bool PROD = false>
@@ -834,7 +835,7 @@ __global__ __launch_bounds__(BEOM_BLOCK) void k_update_uv(DevView d, int ilay_on
 //      place as well (the first update of other workgroups still reads the old one).
 //      Algorithmic traffic: 22 words per cell-layer instead of 14 + 14.
 // first update at one cell; SH = where its shared fields come from
-template <bool FIRST_X, bool PROD, bool STORE, bool INT, class SH>
+template <bool FIRST_X, bool PROD, bool STORE, bool INT, bool SF, class SH>
 __device__ __forceinline__ double uv_first_eval(const DevView &d, const CellDenseT<INT> &c, int ilay, double gene,
                                                 double ramp, double ctim, const SH &sh, bool do_store = true,
                                                 const double *pre = nullptr, bool zv = false) {
@@ -846,15 +847,15 @@ __device__ __forceinline__ double uv_first_eval(const DevView &d, const CellDens
     double *const *dm = FIRST_X ? d.dmx : d.dmy;
     const UVio io{FIRST_X ? d.u : d.v, FIRST_X ? d.u_alt : d.v_alt, FIRST_X ? d.h_u : d.h_v,
                   dm[0], dm[1], dm[2], dm[3]};
-    if (pre) return uv_core<FIRST_X, PROD, STORE>(c, d, ilay, gene, ramp, ctim, 0, io, pre[1], pre[2], pre[3], pre[4],
+    if (pre) return uv_core<FIRST_X, PROD, STORE, SF>(c, d, ilay, gene, ramp, ctim, 0, io, pre[1], pre[2], pre[3], pre[4],
                                                   sh, do_store, pre, zv);
-    return uv_core<FIRST_X, PROD, STORE>(c, d, ilay, gene, ramp, ctim, 0, io, LL(hq, ipnt, ilay),
+    return uv_core<FIRST_X, PROD, STORE, SF>(c, d, ilay, gene, ramp, ctim, 0, io, LL(hq, ipnt, ilay),
                                          LL(hq, cb, ilay), LL(hq, ca, ilay), LL(hq, cd, ilay), sh, do_store);
 }
 
 // boundary workgroups: new first-component transport seen by a NEIGHBOUR lookup of the local
 // target (a, b) — wraps / sentinel applied, everything from global memory
-template <bool FIRST_X, bool PROD>
+template <bool FIRST_X, bool PROD, bool SF>
 __device__ __forceinline__ double uv_first_halo(const DevView &d, int a, int b, int ilay, double gene,
                                                 double ramp, double ctim) {
     if (d.xper) { if (a == 0) a = d.L - 1; else if (a == d.L) a = 1; }
@@ -866,7 +867,7 @@ __device__ __forceinline__ double uv_first_halo(const DevView &d, int a, int b, 
     const int cb = FIRST_X ? h.template nb<5>() : h.template nb<7>();
     const int ca = FIRST_X ? h.template nb<3>() : h.template nb<1>();
     const ShGlobal sh{d, h.ipnt, cb, ca, ilay};
-    return uv_first_eval<FIRST_X, PROD, false, false>(d, h, ilay, gene, ramp, ctim, sh);
+    return uv_first_eval<FIRST_X, PROD, false, false, SF>(d, h, ilay, gene, ramp, ctim, sh);
 }
 
 static_assert(MV_TX == UV_TX && UV_TY % MV_TY == 0, "lean_d2h: every tile of k_mont_visc lies inside one tile of k_uv_fused");
@@ -891,7 +892,7 @@ __device__ __forceinline__ void uv_pre_load(const DevView &d, const CellDenseT<t
     if (gene != 0.0) { pre[5] = LL(dm[0], ipnt, ilay); pre[6] = LL(dm[1], ipnt, ilay); pre[7] = LL(dm[2], ipnt, ilay); }
 }
 
-template <bool FIRST_X, bool ZV>
+template <bool FIRST_X, bool ZV, bool SF>
 __device__ __forceinline__ void body_uv_fused_staged(const DevView &d, int x0, int y0, int ilay, double gene,
                                                      double ramp, double ctim, double (*s_h)[UV_LDX], UVstage *s_f,
                                                      double (*s_hl)[UV_HLDX]) {
@@ -965,11 +966,11 @@ __device__ __forceinline__ void body_uv_fused_staged(const DevView &d, int x0, i
     for (int q = 0; q < UV_Q; ++q) {
         const int r = wy + UV_WAVES * q;
         const ShLds<FIRST_X> sh{s_f, s_hl, r + 1, lx + 1, d.ocrp, hs2};
-        s_h[r + ROFF][lx + COFF] = uv_first_eval<FIRST_X, true, true, true>(d, c[q], ilay, gene, ramp, ctim, sh, wr[q], pre[q], ZV);
+        s_h[r + ROFF][lx + COFF] = uv_first_eval<FIRST_X, true, true, true, SF>(d, c[q], ilay, gene, ramp, ctim, sh, wr[q], pre[q], ZV);
     }
     if (rr1 >= 0) {
         const ShLds<FIRST_X> sh{s_f, s_hl, rb - (y0 - 1), ra - (x0 - 1), d.ocrp, hs2};
-        s_h[rr1][cc1] = uv_first_eval<FIRST_X, true, false, true>(d, hc, ilay, gene, ramp, ctim, sh, true, preR, ZV);
+        s_h[rr1][cc1] = uv_first_eval<FIRST_X, true, false, true, SF>(d, hc, ilay, gene, ramp, ctim, sh, true, preR, ZV);
     }
     __syncthreads();
     // ---- second component, transport of the first from LDS
@@ -987,13 +988,13 @@ __device__ __forceinline__ void body_uv_fused_staged(const DevView &d, int x0, i
             q0 = s_h[r][lx + 1]; qb = s_h[r][lx]; qa = s_h[r + 1][lx + 1]; qd = s_h[r + 1][lx];
         }
         const ShLds<!FIRST_X> sh{s_f, s_hl, r + 1, lx + 1, d.ocrp, hs2};
-        uv_core<!FIRST_X, true, true>(c[q], d, ilay, gene, ramp, ctim, 0, io, q0, qb, qa, qd, sh, true, pre2[q], ZV);
+        uv_core<!FIRST_X, true, true, SF>(c[q], d, ilay, gene, ramp, ctim, 0, io, q0, qb, qa, qd, sh, true, pre2[q], ZV);
     }
 }
 
 // Every other workgroup — boundary tiles (wraps, sentinel, masks), and all tiles of the v_cc/v_ll
 // form (PROD = false) — reads global memory as the unfused sweeps do.
-template <bool FIRST_X, bool PROD, bool INT>
+template <bool FIRST_X, bool PROD, bool INT, bool SF>
 __device__ __forceinline__ void body_uv_fused(const DevView &d, int x0, int y0, int ilay, double gene,
                                               double ramp, double ctim, double (*s_h)[UV_LDX]) {
     const int tid = threadIdx.x;
@@ -1016,10 +1017,10 @@ __device__ __forceinline__ void body_uv_fused(const DevView &d, int x0, int y0, 
             const int cb = FIRST_X ? c[q].template nb<5>() : c[q].template nb<7>();
             const int ca = FIRST_X ? c[q].template nb<3>() : c[q].template nb<1>();
             const ShGlobal sh{d, c[q].ipnt, cb, ca, ilay};
-            hnew = uv_first_eval<FIRST_X, PROD, true, INT>(d, c[q], ilay, gene, ramp, ctim, sh, wr[q]);
+            hnew = uv_first_eval<FIRST_X, PROD, true, INT, SF>(d, c[q], ilay, gene, ramp, ctim, sh, wr[q]);
             if (!INT) {     // orphan column/row are wrap TARGETS: stage what a neighbour lookup returns
                 if ((d.xper && i == d.L) || (d.yper && !d.slab && j == d.M))
-                    hnew = uv_first_halo<FIRST_X, PROD>(d, i, j, ilay, gene, ramp, ctim);
+                    hnew = uv_first_halo<FIRST_X, PROD, SF>(d, i, j, ilay, gene, ramp, ctim);
             }
         }
         s_h[r + ROFF][lx + COFF] = hnew;
@@ -1035,7 +1036,7 @@ __device__ __forceinline__ void body_uv_fused(const DevView &d, int x0, int y0, 
         if (rr >= 0) {
             const int a = (FIRST_X ? x0 : x0 - 1) + cc;
             const int b = (FIRST_X ? y0 - 1 : y0) + rr;
-            s_h[rr][cc] = uv_first_halo<FIRST_X, PROD>(d, a, b, ilay, gene, ramp, ctim);
+            s_h[rr][cc] = uv_first_halo<FIRST_X, PROD, SF>(d, a, b, ilay, gene, ramp, ctim);
         }
     }
     __syncthreads();
@@ -1058,7 +1059,7 @@ __device__ __forceinline__ void body_uv_fused(const DevView &d, int x0, int y0, 
         const int cb = !FIRST_X ? c[q].template nb<5>() : c[q].template nb<7>();
         const int ca = !FIRST_X ? c[q].template nb<3>() : c[q].template nb<1>();
         const ShGlobal sh{d, c[q].ipnt, cb, ca, ilay};
-        uv_core<!FIRST_X, PROD, true>(c[q], d, ilay, gene, ramp, ctim, 0, io, q0, qb, qa, qd, sh);
+        uv_core<!FIRST_X, PROD, true, SF>(c[q], d, ilay, gene, ramp, ctim, 0, io, q0, qb, qa, qd, sh);
     }
 }
 
@@ -1089,7 +1090,7 @@ struct ShLdsEdge {                                   // field order in the stage
     template <bool X> __device__ __forceinline__ double d2h_b() const { return LL(X ? d.d2hx : d.d2hy, cb, ilay); }
 };
 
-template <bool FIRST_X>
+template <bool FIRST_X, bool SF>
 __device__ __forceinline__ void body_uv_fused_edge(const DevView &d, int x0, int y0, int ilay, double gene, double ramp,
                                                    double ctim, double (*s_h)[UV_LDX], UVstage *s_f, double (*s_hl)[UV_HLDX]) {
     static_assert(sizeof(double) * UV_HROWS * UV_HLDX >= sizeof(UVstage), "the hlay image fits the widened hlay stage");
@@ -1146,11 +1147,11 @@ __device__ __forceinline__ void body_uv_fused_edge(const DevView &d, int x0, int
                 // so the cell's own update reads global memory; and what it stages is what a lookup of it returns
                 const int ca = FIRST_X ? c[q].template nb<3>() : c[q].template nb<1>();
                 const ShGlobal sh{d, c[q].ipnt, cb, ca, ilay};
-                (void)uv_first_eval<FIRST_X, true, true, false>(d, c[q], ilay, gene, ramp, ctim, sh, wr[q]);
-                hnew = uv_first_halo<FIRST_X, true>(d, i, j, ilay, gene, ramp, ctim);
+                (void)uv_first_eval<FIRST_X, true, true, false, SF>(d, c[q], ilay, gene, ramp, ctim, sh, wr[q]);
+                hnew = uv_first_halo<FIRST_X, true, SF>(d, i, j, ilay, gene, ramp, ctim);
             } else {
                 const ShLdsEdge<FIRST_X> sh{s_f, s_hs, r + 1, lx + 1, d, c[q].ipnt, cb, ilay};
-                hnew = uv_first_eval<FIRST_X, true, true, false>(d, c[q], ilay, gene, ramp, ctim, sh, wr[q]);
+                hnew = uv_first_eval<FIRST_X, true, true, false, SF>(d, c[q], ilay, gene, ramp, ctim, sh, wr[q]);
             }
         }
         s_h[r + ROFF][lx + COFF] = hnew;
@@ -1167,13 +1168,13 @@ __device__ __forceinline__ void body_uv_fused_edge(const DevView &d, int x0, int
                 if (a != ga || b != gb) {
                     // a ring position beyond the periodic seam: the image around it is not the neighbourhood of the
                     // cell it stands for (the wraps act on every lookup anew) — the rare global path
-                    val = uv_first_halo<FIRST_X, true>(d, ga, gb, ilay, gene, ramp, ctim);
+                    val = uv_first_halo<FIRST_X, true, SF>(d, ga, gb, ilay, gene, ramp, ctim);
                 } else {
                     CellDenseT<false> h;
                     h.set_cell(d, a, b);
                     const int cb = FIRST_X ? h.template nb<5>() : h.template nb<7>();
                     const ShLdsEdge<FIRST_X> sh{s_f, s_hs, gb - (y0 - 1), ga - (x0 - 1), d, h.ipnt, cb, ilay};
-                    val = uv_first_eval<FIRST_X, true, false, false>(d, h, ilay, gene, ramp, ctim, sh);
+                    val = uv_first_eval<FIRST_X, true, false, false, SF>(d, h, ilay, gene, ramp, ctim, sh);
                 }
             }
             s_h[rr][cc] = val;
@@ -1195,10 +1196,10 @@ __device__ __forceinline__ void body_uv_fused_edge(const DevView &d, int x0, int
         if ((d.xper && i == d.L) || (d.yper && !d.slab && y0 + r == d.M)) {      // orphan column / row: see above
             const int ca = !FIRST_X ? c[q].template nb<3>() : c[q].template nb<1>();
             const ShGlobal sh{d, c[q].ipnt, cb, ca, ilay};
-            uv_core<!FIRST_X, true, true>(c[q], d, ilay, gene, ramp, ctim, 0, io, q0, qb, qa, qd, sh);
+            uv_core<!FIRST_X, true, true, SF>(c[q], d, ilay, gene, ramp, ctim, 0, io, q0, qb, qa, qd, sh);
         } else {
             const ShLdsEdge<!FIRST_X> sh{s_f, s_hs, r + 1, lx + 1, d, c[q].ipnt, cb, ilay};
-            uv_core<!FIRST_X, true, true>(c[q], d, ilay, gene, ramp, ctim, 0, io, q0, qb, qa, qd, sh);
+            uv_core<!FIRST_X, true, true, SF>(c[q], d, ilay, gene, ramp, ctim, 0, io, q0, qb, qa, qd, sh);
         }
     }
 }
@@ -1209,7 +1210,7 @@ __device__ __forceinline__ void body_uv_fused_edge(const DevView &d, int x0, int
 #else
 #define UV_OCC_ATTR
 #endif
-template <bool FIRST_X, bool PROD, bool ZV = false>
+template <bool FIRST_X, bool PROD, bool ZV = false, bool SF = false>
 __global__ __launch_bounds__(UV_BLOCK) UV_OCC_ATTR void k_uv_fused(DevView d, double gene, double ramp, double ctim) {
     __shared__ double s_h[UV_TY + 1][UV_LDX];
     __shared__ UVstage s_f[PROD ? 4 : 1];                    // (ZV: the interior workgroups use two of them, the edge ones all four)
@@ -1221,10 +1222,10 @@ __global__ __launch_bounds__(UV_BLOCK) UV_OCC_ATTR void k_uv_fused(DevView d, do
     const int ilay = blockIdx.y + 1;
     const bool interior = x0 - 1 >= 2 && x0 + UV_TX <= d.L - 2 && y0 - 1 >= 2 && y0 + UV_TY <= d.M - 2
                           && y0 - 1 + d.joff >= 2 && y0 + UV_TY + d.joff <= d.Mg - 2 && tile_regular(d, x0, y0, UV_TY);
-    if (interior && PROD) body_uv_fused_staged<FIRST_X, ZV>(d, x0, y0, ilay, gene, ramp, ctim, s_h, s_f, s_hl);
-    else if (interior) body_uv_fused<FIRST_X, PROD, true>(d, x0, y0, ilay, gene, ramp, ctim, s_h);
-    else if (PROD && !d.edge_global) body_uv_fused_edge<FIRST_X>(d, x0, y0, ilay, gene, ramp, ctim, s_h, s_f, s_hl);
-    else body_uv_fused<FIRST_X, PROD, false>(d, x0, y0, ilay, gene, ramp, ctim, s_h);
+    if (interior && PROD) body_uv_fused_staged<FIRST_X, ZV, SF>(d, x0, y0, ilay, gene, ramp, ctim, s_h, s_f, s_hl);
+    else if (interior) body_uv_fused<FIRST_X, PROD, true, SF>(d, x0, y0, ilay, gene, ramp, ctim, s_h);
+    else if (PROD && !d.edge_global) body_uv_fused_edge<FIRST_X, SF>(d, x0, y0, ilay, gene, ramp, ctim, s_h, s_f, s_hl);
+    else body_uv_fused<FIRST_X, PROD, false, SF>(d, x0, y0, ilay, gene, ramp, ctim, s_h);
 }
 static inline dim3 uv_fused_grid(const DevView &d) {
     return dim3(TileMap(d, UV_TX, UV_TY).blocks(), (unsigned)d.nlay, 1);

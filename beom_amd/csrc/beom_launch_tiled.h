@@ -19,15 +19,15 @@ static bool TFN(raw_mont_visc)(beom_engine *E, bool leith) {
 static void TFN(raw_uv_fused)(beom_engine *E, bool first_x, bool prod, bool zv, double gene, double ramp, double ctim) {
     const dim3 g = TNS::uv_fused_grid(E->d), b(TNS::kUvBlock);
     DevView &d = E->d;
-    if (first_x) {
-        if (zv) hipLaunchKernelGGL((TNS::k_uv_fused<true, true, true>), g, b, 0, E->stream, d, gene, ramp, ctim);
-        else if (prod) hipLaunchKernelGGL((TNS::k_uv_fused<true, true>), g, b, 0, E->stream, d, gene, ramp, ctim);
-        else hipLaunchKernelGGL((TNS::k_uv_fused<true, false>), g, b, 0, E->stream, d, gene, ramp, ctim);
-    } else {
-        if (zv) hipLaunchKernelGGL((TNS::k_uv_fused<false, true, true>), g, b, 0, E->stream, d, gene, ramp, ctim);
-        else if (prod) hipLaunchKernelGGL((TNS::k_uv_fused<false, true>), g, b, 0, E->stream, d, gene, ramp, ctim);
-        else hipLaunchKernelGGL((TNS::k_uv_fused<false, false>), g, b, 0, E->stream, d, gene, ramp, ctim);
-    }
+#define UV_GO(fx, pr, z, sf) hipLaunchKernelGGL((TNS::k_uv_fused<fx, pr, z, sf>), g, b, 0, E->stream, d, gene, ramp, ctim)
+#define UV_PICK(fx) do { \
+        if (d.stress_fold) { if (zv) UV_GO(fx, true, true, true); else if (prod) UV_GO(fx, true, false, true); else UV_GO(fx, false, false, true); } \
+        else { if (zv) UV_GO(fx, true, true, false); else if (prod) UV_GO(fx, true, false, false); else UV_GO(fx, false, false, false); } \
+    } while (0)
+    // (stress_fold: distribute_stress formed inside the sweep — its own instantiations, so that the unforced ones stay lean)
+    if (first_x) UV_PICK(true); else UV_PICK(false);
+#undef UV_PICK
+#undef UV_GO
 }
 #undef TFN
 #undef TFN2
