@@ -192,6 +192,7 @@ def load(path: Optional[str] = None) -> C.CDLL:
                                             C.POINTER(BeomStatics), C.POINTER(BeomStatics), C.POINTER(MH), cp, ci]
     lib.beom_multi_create_local_ex.argtypes = [C.POINTER(BeomParams), ci, ci, ci, ci, ci, ci, C.c_void_p,
                                                C.POINTER(BeomStatics), C.POINTER(BeomStatics), C.POINTER(MH), cp, ci]
+    lib.beom_multi_set_open_boundaries_local.argtypes = [MH, ci, C.POINTER(ci), ci, C.POINTER(ci), cp, ci]
     lib.beom_multi_upload_local.argtypes = [MH, C.POINTER(BeomState), C.POINTER(BeomState), cp, ci]
     lib.beom_multi_download_local.argtypes = [MH, C.POINTER(BeomState), C.POINTER(BeomState), cp, ci]
     for name in ("beom_multi_create", "beom_multi_destroy", "beom_multi_count", "beom_multi_band",
@@ -199,7 +200,8 @@ def load(path: Optional[str] = None) -> C.CDLL:
                  "beom_multi_stats", "beom_multi_create_ex", "beom_multi_describe", "beom_multi_engine",
                  "beom_multi_download_outputs", "beom_multi_download_diag", "beom_multi_set_open_boundaries",
                  "beom_multi_set_option", "beom_multi_profile_start", "beom_multi_profile_stop", "beom_rccl_unique_id", "beom_rccl_version",
-                 "beom_multi_window", "beom_multi_create_local", "beom_multi_create_local_ex", "beom_multi_upload_local", "beom_multi_download_local"):
+                 "beom_multi_window", "beom_multi_create_local", "beom_multi_create_local_ex", "beom_multi_set_open_boundaries_local",
+                 "beom_multi_upload_local", "beom_multi_download_local"):
         getattr(lib, name).restype = ci
     for name in ("beom_device_count", "beom_create", "beom_destroy", "beom_upload_state",
                  "beom_download_state", "beom_download_scratch", "beom_step", "beom_sync",
@@ -228,7 +230,8 @@ EXPORTS = ("beom_abi_version", "beom_device_count", "beom_device_pci_bus_id", "b
            "beom_multi_stats", "beom_multi_create_ex", "beom_multi_describe", "beom_multi_engine",
            "beom_multi_download_outputs", "beom_multi_download_diag", "beom_multi_set_open_boundaries",
            "beom_multi_set_option", "beom_multi_profile_start", "beom_multi_profile_stop", "beom_rccl_unique_id", "beom_rccl_version",
-           "beom_multi_window", "beom_multi_create_local", "beom_multi_create_local_ex", "beom_multi_upload_local", "beom_multi_download_local")
+           "beom_multi_window", "beom_multi_create_local", "beom_multi_create_local_ex", "beom_multi_set_open_boundaries_local",
+           "beom_multi_upload_local", "beom_multi_download_local")
 
 STATE_NAMES = ("hlay", "u", "v", "h_u", "h_v", "rs_h", "dmdx", "dmdy", "v_cc", "v_ll",
                "tt3d", "tb3d", "tu3d")
@@ -624,6 +627,12 @@ class BandEngine(MultiEngine):
             transport | (XCHG_LOOPBACK if loopback else 0), idbuf, C.byref(st), C.byref(so) if so is not None else None,
             C.byref(self.h), self._err, ERRLEN)
         self._check(rc)
+        if bool(f.flag_nudging) and float(p_global.mcbc) < 0.5:       # no_gradient_obc (:2613): the segments of this window's rows
+            seg = lambda x: np.ascontiguousarray(x.segm, dtype=np.int32) if (x is not None and x.segm is not None) else None
+            sw, so_ = seg(f), seg(orphan)
+            self._check(self.lib.beom_multi_set_open_boundaries_local(
+                self.h, 0 if sw is None else sw.shape[1], None if sw is None else _ip(sw),
+                0 if so_ is None else so_.shape[1], None if so_ is None else _ip(so_), self._err, ERRLEN))
         if upload:
             self.upload()
 

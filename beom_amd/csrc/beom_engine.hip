@@ -1096,6 +1096,7 @@ int beom_step_phase(beom_handle E, int tstp, double tres, double dtd8, double dt
     if (!E) { set_err(errm, errm_len, "null handle"); return -1; }
     HIP_TRY(hipSetDevice(E->device));
     DevView &d = E->d;
+    if (E->P.flag_nudging && E->P.mcbc < 0.5 && !E->obc && !E->obc_set) { set_err(errm, errm_len, "beom_step_phase: mcbc = 0 with nudging needs beom_set_open_boundaries (no_gradient_obc, private_mod.f95:2613-2679)"); return -6; }
     const StepScalars s = step_scalars(E, tstp, tres, dtd8, dt_r, rsta, n_3d);
     const bool south = d.slab && d.joff > 0, north = d.slab && d.joff + d.M < d.Mg;
     if (!s.fused_uv || !(south || north) || d.M < 4 * kEdgeRows || phase < 1 || phase > 3 || E->obc || E->lid) {

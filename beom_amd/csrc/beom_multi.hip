@@ -423,12 +423,8 @@ int check_frame(const beom_params *prm, int nb, int yper, bool global_arrays, bo
     const int ring_rows = yper ? prm->mm : Mg;
     // every band sends its outermost kGhost owned rows; band 0 of a ring also lends rows 1..kMiniLo to the companion frame
     if (ring_rows < nb * (yper ? (kGhost > kMiniLo ? kGhost : kMiniLo) : kGhost + 1)) { m_err(errm, errm_len, "beom_multi: %d rows are too few for %d bands", ring_rows, nb); return -3; }
-    if (prm->flag_nudging && prm->mcbc < 0.5 && !global_arrays) {
-        // (the segment table is made of global cell indices: beom_multi_set_open_boundaries deals it to the bands of a handle
-        //  created from the global arrays — a chain or a ring; a rank that holds only its window has no such table)
-        m_err(errm, errm_len, "beom_multi: mcbc = 0 (no_gradient_obc) needs a handle created from the global arrays");
-        return -4;
-    }
+    (void)global_arrays;      // (mcbc = 0: a handle from global arrays gets the global segment table, beom_multi_set_open_boundaries; a
+                              //  rank that holds only its window brings the segments of its own rows, ..._local; beom_step refuses until then)
     if (yper && prm->svis > 0.0) { m_err(errm, errm_len, "beom_multi: biharmonic viscosity on a frame periodic in y runs on a single-device handle only"); return -4; }
     return 0;
 }
@@ -1096,6 +1092,48 @@ int beom_multi_set_open_boundaries(beom_multi_handle M, int nseg, const int32_t 
         M_RC(beom_set_open_boundaries(k < 0 ? M->mini : M->eng[k], nloc, nloc ? tab.data() : nullptr, errm, errm_len));
     }
     return 0;
+}
+
+// The same for a handle that holds ONE band's window (beom_multi_create_local): the caller found the segments of its own
+// rows — the finder (index_boundary_points, private_mod.f95:1060-1240) looks at a cell and its four neighbours only, so a
+// window's rows (ghost rows included, the row below and above them known) give exactly the global table's entries of those
+// rows — with cell indices of the window.  Band 0 of a ring also passes the segments of the orphan row mm+1 (indices of a
+// one-row frame); the companion frame's table is put together here from both.
+int beom_multi_set_open_boundaries_local(beom_multi_handle M, int nseg, const int32_t *segm, int nseg_orphan, const int32_t *segm_orphan,
+                                         char *errm, int errm_len) {
+    if (!M || nseg < 0 || (nseg > 0 && !segm) || nseg_orphan < 0 || (nseg_orphan > 0 && !segm_orphan)) { m_err(errm, errm_len, "beom_multi_set_open_boundaries_local: bad arguments"); return -1; }
+    if (!M->local_mode) { m_err(errm, errm_len, "beom_multi_set_open_boundaries_local: this handle was created from global arrays"); return -3; }
+    M_RC(beom_set_open_boundaries(M->eng[0], nseg, nseg ? segm : nullptr, errm, errm_len));
+    if (!M->mini) return 0;
+    const int L = M->P.lm + 1, gs = M->band[0].gs;
+    std::vector<std::array<int32_t, 18>> rowsv;
+    // window row jl (1-based) -> row of the companion frame, 0 = not there
+    auto from_window = [&](int jl) { return (jl >= 1 && jl <= gs) ? kMiniLo + jl : (jl > gs && jl <= gs + kMiniLo) ? jl - gs : 0; };
+    auto from_orphan = [&](int jl) { return jl == 1 ? kMiniLo + kGhost + 1 : 0; };
+    for (int src = 0; src < 2; ++src) {
+        const int n = src ? nseg_orphan : nseg;
+        const int32_t *tab = src ? segm_orphan : segm;
+        for (int is = 0; is < n; ++is)
+            for (int pass = 0; pass < 2; ++pass) {
+                const int cu = pass == 0 ? 10 : 1, cs = pass == 0 ? 16 : 13;
+                const int32_t qu = tab[(size_t)is + (size_t)n * (cu - 1)], qs = tab[(size_t)is + (size_t)n * (cs - 1)];
+                if (qu < 1) continue;
+                const int mu = src ? from_orphan((qu - 1) / L + 1) : from_window((qu - 1) / L + 1);
+                const int ms = qs > 0 ? (src ? from_orphan((qs - 1) / L + 1) : from_window((qs - 1) / L + 1)) : 0;
+                if (!mu || (qs > 0 && !ms)) continue;
+                std::array<int32_t, 18> r;
+                for (int c = 1; c <= 18; ++c) r[(size_t)c - 1] = tab[(size_t)is + (size_t)n * (c - 1)];
+                r[0] = r[9] = -1; r[12] = r[15] = r[6] = 0;
+                r[(size_t)cu - 1] = (int32_t)((qu - 1) % L + 1 + (long long)(mu - 1) * L);
+                r[(size_t)cs - 1] = qs > 0 ? (int32_t)((qs - 1) % L + 1 + (long long)(ms - 1) * L) : 0;
+                rowsv.push_back(r);
+            }
+    }
+    const int nloc = (int)rowsv.size();
+    std::vector<int32_t> t2((size_t)nloc * 18);
+    for (int is = 0; is < nloc; ++is)
+        for (int c = 0; c < 18; ++c) t2[(size_t)is + (size_t)nloc * c] = rowsv[(size_t)is][(size_t)c];
+    return beom_set_open_boundaries(M->mini, nloc, nloc ? t2.data() : nullptr, errm, errm_len);
 }
 
 int beom_multi_download_diag(beom_multi_handle M, float *pvor4, float *mont4, float *vcc4, char *errm, int errm_len) {

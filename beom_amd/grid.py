@@ -184,16 +184,19 @@ def index_grid_points(p: Params, h_2d: np.ndarray, window=None):
     return dict(neig=neig, subc=subc, posc=posc, h_th=h_th, **mk)
 
 
-def index_boundary_points(p: Params, nd: np.ndarray, h_2d: np.ndarray) -> np.ndarray:
+def index_boundary_points(p: Params, nd: np.ndarray, h_2d: np.ndarray, band: bool = False) -> np.ndarray:
     """private_mod.f95:1060-1240 — the table of nudged open-boundary segments used by
     no_gradient_obc (:2613-2679).  nd = nudg.bin content [lm+2, mm+2, 3] (real*4).
     Returns int32 [18, nseg] (the bytes of Fortran segm(nseg, 18)); raises like the reference
-    when no segment exists."""
+    when no segment exists.  band: the frame is a band of rows of a taller frame (read_input_data's
+    window): its row 0 is the (wet) row below the band — looked at, neither packed nor searched."""
     lm, mm = p.lm, p.mm
     wet = h_2d > p.hdry                                   # offset 1: frame (i, j) -> [i+1, j+1]
     W = lambda i, j: bool(wet[i + 1, j + 1])
     # packed numbering exactly as in index_grid_points, WITHOUT the periodic overwrites (:1088-1097)
     incl = wet[1:lm + 3, 1:mm + 3] | wet[0:lm + 2, 1:mm + 3] | wet[1:lm + 3, 0:mm + 2] | wet[0:lm + 2, 0:mm + 2]
+    if band:
+        incl[:, 0] = False
     indc = np.zeros((lm + 4, mm + 4), dtype=np.int64)
     flat = np.zeros(incl.size, dtype=np.int64)
     order = np.flatnonzero(incl.ravel(order="F"))
@@ -203,7 +206,7 @@ def index_boundary_points(p: Params, nd: np.ndarray, h_2d: np.ndarray) -> np.nda
     tiny = np.finfo(np.float32).tiny
     xopen, yopen = float(p.xper) < 0.5, float(p.yper) < 0.5
     rows = []
-    for j in range(0, mm + 2):
+    for j in range(1 if band else 0, mm + 2):
         for i in range(0, lm + 2):
             if W(i, j) and not W(i - 1, j) and xopen and nd[i, j, IX_U] > tiny and nd[i - 1, j, IX_U] > tiny:       # west
                 rows.append([I(i, j), i, j, 1, 0, 1, I(i - 1, j), i - 1, j, I(i, j), i, j, I(i + 1, j), i + 1, j, I(i + 1, j), i + 1, j])
@@ -502,6 +505,17 @@ def read_input_data(p: Params, idir: Optional[str] = None,
         flag_nudging = bool(np.any(nudg > 1e-9))
         if flag_nudging and window is None:
             segm = index_boundary_points(p, nd, h_2d)               # :868-871
+        elif window is not None and float(p.mcbc) < 0.5:
+            # a band of rows finds the segments of its own rows (the finder looks at a cell and its four neighbours; the rows
+            # below and above the band are in the frame's margins, dry only where they are the whole frame's margins)
+            pseg = p
+            if "yper" in window:                                    # (a band never wraps by itself, but the frame may: no N/S segments then)
+                pseg = Params.from_json(p.to_json())
+                pseg.lits["yper"] = window["yper"]
+            try:
+                segm = index_boundary_points(pseg, nd, h_2d, band=True)
+            except ValueError:
+                segm = None                                         # none in these rows
         fnud[IX_N, :, 1:] = hlay[:, 1:]                             # :874-881
     it = get("init", (lm + 2, mm + 2, nlay, 3))
     has["init"] = it is not None

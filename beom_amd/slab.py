@@ -253,8 +253,24 @@ def build_rows(recipe, glob: dict, j0: int, j1: int) -> Fields:
     lp.mm = j1 - j0
     lp.ndeg = (p.lm + 1) * (j1 - j0 + 1)
     lp.lits["yper"] = "0."                                        # a band never wraps by itself
-    win = dict(glob, bottom_margin=(j0 - 1 == 0), top_margin=(j1 == p.mm + 1))
+    win = dict(glob, bottom_margin=(j0 - 1 == 0), top_margin=(j1 == p.mm + 1), yper=p.lits["yper"])
     return read_input_data(lp, files=recipe.rows(j0 - 1, j1), window=win)
+
+
+def _join_segm(pieces: List[Fields]) -> Optional[np.ndarray]:
+    """Open-boundary segments (Fields.segm, int32 [18, nseg]) of pieces stacked south to north: cell indices and row numbers
+    shifted by the rows below the piece (segments run along rows: both ends of one lie in the same piece or the next row)."""
+    out, cells, rows = [], 0, 0
+    for q in pieces:
+        if q.segm is not None and q.segm.size:
+            t = np.array(q.segm, dtype=np.int64)
+            for c in (0, 6, 9, 12, 15):                  # columns 1, 7, 10, 13, 16 of segm(nseg, 18): cell, then its (i, j)
+                t[c] = np.where(t[c] > 0, t[c] + cells, t[c])
+                t[c + 2] = t[c + 2] + rows
+            out.append(t)
+        cells += q.p.ndeg
+        rows += q.p.mm + 1
+    return np.ascontiguousarray(np.concatenate(out, axis=1).astype(np.int32)) if out else None
 
 
 def _join(pieces: List[Fields]) -> Fields:
@@ -272,7 +288,7 @@ def _join(pieces: List[Fields]) -> Fields:
     lp.mm = sum(q.p.mm + 1 for q in pieces) - 1
     lp.ndeg = sum(q.p.ndeg for q in pieces)
     return Fields(p=lp, posc=np.concatenate([q.posc for q in pieces]), w_ti=f0.w_ti.copy(), bodf=f0.bodf.copy(),
-                  invf=f0.invf, flag_nudging=any(q.flag_nudging for q in pieces), has=dict(f0.has), **kw)
+                  invf=f0.invf, flag_nudging=any(q.flag_nudging for q in pieces), has=dict(f0.has), segm=_join_segm(pieces), **kw)
 
 
 def _with_tables(f: Fields, t: Dict[str, np.ndarray]) -> Fields:

@@ -378,6 +378,12 @@ int beom_multi_create_local_ex(const beom_params *prm, int nb, int band, int dev
                                int transport_and_flags, const void *xchg_id,
                                const beom_statics *window, const beom_statics *orphan,
                                beom_multi_handle *out, char *errm, int errm_len);
+/* no_gradient_obc (mcbc = 0) for a handle that holds one band's window: the segments of the window's own rows, as
+ * beom_set_open_boundaries takes them, with cell indices of the window (the finder of private_mod.f95:1060-1240 looks at a
+ * cell and its four neighbours only, so a rank finds them from its rows alone); band 0 of a frame periodic in y adds those of
+ * the orphan row mm+1 (indices of a one-row frame; else 0 / NULL).  nseg = 0: this band holds no segment. */
+int beom_multi_set_open_boundaries_local(beom_multi_handle h, int nseg, const int32_t *segm, int nseg_orphan, const int32_t *segm_orphan,
+                                         char *errm, int errm_len);
 int beom_multi_upload_local(beom_multi_handle h, const beom_state *window, const beom_state *orphan,
                             char *errm, int errm_len);
 int beom_multi_download_local(beom_multi_handle h, beom_state *window, beom_state *orphan,
