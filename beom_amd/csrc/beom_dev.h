@@ -35,6 +35,13 @@ struct DevView {
     const int32_t *pk_of;         // slot -> packed index (ipnt of the caller), 0 = not a packed cell; null unless embedded
     const unsigned char *reg4;    // per 64 x 4 tile: 1 = every cell within 3 cells of it is wet interior with unit masks
     int reg_nx;                   // tiles per row of reg4
+    // nudged frames on the rectangle: per 64 x 4 tile, bit iv-1 = some cell of the tile has a non-zero relaxation rate
+    // nudg(:, iv) (iv = 1 eta, 2 u, 3 v).  Sponges are a few rows or columns: elsewhere a wave of update_h learns from ONE
+    // byte that its 64 rates are zero instead of loading them; null = no table (load always).  (The momentum sweep does not
+    // use it: the look-up cost k_uv_fused 6-9 VGPRs in every instantiation — three waves per SIMD for the zero-viscosity
+    // forms — for 2.6 % on the one frame it helped.)
+    const unsigned char *ngt;
+    int ngt_nx;
     int joff, Mg, slab;           // j-slab: local row j is global row j + joff of Mg = mm_global+1 rows
     // rows a launch may WRITE: up to two strips [jlo, jhi] (local, inclusive); default one strip 1..M.
     // Used to split a step into an interior pass and an edge pass around the ghost-row exchange.
@@ -186,6 +193,7 @@ template <int K> struct NbOff {
 // table woff): neighbours by arithmetic, every mask 1 — no table traffic, as in the dense interior.
 struct CellPackedInt {
     static constexpr bool kLanesAreRowNeighbours = true;
+    static constexpr bool kHasIJ = false;
     int ipnt, dN, dS;
     const DevView *dv;
     template <int K> __device__ __forceinline__ int nb() const {
@@ -205,6 +213,7 @@ struct CellPackedInt {
 
 struct CellGather {
     static constexpr bool kLanesAreRowNeighbours = false;
+    static constexpr bool kHasIJ = false;
     int ipnt;
     const int32_t *row;
     const DevView *dv;
@@ -263,6 +272,7 @@ struct CellDenseT {
     // lane l and lane l+1 of an INTERIOR wave hold cells (i, j) and (i+1, j): an east/west
     // neighbour value is one wavefront shuffle away instead of one more load
     static constexpr bool kLanesAreRowNeighbours = INTERIOR;
+    static constexpr bool kHasIJ = true;
     int i, j, ipnt, L, M, P, xper, yper;
     int jg, Mg, ywrap;            // global row / row count (masks); y wrap only when not a slab
     const DevView *dv;            // embedded frames: masks from the caller's arrays
@@ -339,3 +349,13 @@ struct CellDenseT {
     __device__ __forceinline__ int isub() const { return i; }
 };
 using CellDense = CellDenseT<false>;
+
+// relaxation rate nudg(ipnt, IV) of a cell (IV = 1 eta, 2 u, 3 v): contexts that know the cell's (i, j) ask the tile table
+// first (DevView::ngt) — away from the sponges a zero costs one byte per wave instead of a double per lane
+template <int IV, class C>
+__device__ __forceinline__ double nudg_rate(const C &c, const DevView &d) {
+    if constexpr (C::kHasIJ) {
+        if (d.ngt && !((d.ngt[(long long)((c.j - 1) >> 2) * d.ngt_nx + ((c.i - 1) >> 6)] >> (IV - 1)) & 1)) return 0.0;
+    }
+    return d.nudg[(long long)c.ipnt + d.n1 * (IV - 1)];
+}

@@ -54,7 +54,7 @@ __device__ __forceinline__ void body_update_h(const C &c, const DevView &d, doub
     const int c1 = c.template nb<1>(), c3 = c.template nb<3>();
     const double i_dl = d.i_dl;
     const double mkn = c.mk_n();
-    const double ng = FORCED ? NUDG_(ipnt, 1) : 0.0;
+    const double ng = FORCED ? nudg_rate<1>(c, d) : 0.0;
     const int ilay_hi = gridDim.y == 1 ? d.nlay : (int)blockIdx.y + 1;
     const int ilay_lo = gridDim.y == 1 ? 1 : (int)blockIdx.y + 1;
     for (int ilay = ilay_hi; ilay >= ilay_lo; --ilay) {
@@ -685,7 +685,7 @@ __device__ __forceinline__ double uv_core(const C &c, const DevView &d, int ilay
     // nudging rate of this point; the target velocity is fetched only where the rate is not zero (sponges cover a
     // few rows or columns of a frame) or where the sign of an exact zero is at stake
     double f_ng = 0.0;
-    if (d.has_nudg) f_ng = NUDG_(ipnt, IV);
+    if (d.has_nudg) f_ng = NUDG_(ipnt, IV);       // (the tile table of update_h costs this sweep more registers than it saves bytes)
     const double dmd4 = (sh.mont_b() - m_self) * i_dl * d.grav * mask;
     const double pva = sh.pvor_a();
     double rhsi = dmd4 * (1.0 - gene);
@@ -1210,8 +1210,8 @@ __device__ __forceinline__ void body_uv_fused_edge(const DevView &d, int x0, int
 #else
 #define UV_OCC_ATTR
 #endif
-template <bool FIRST_X, bool PROD, bool ZV = false, bool SF = false>
-__global__ __launch_bounds__(UV_BLOCK) UV_OCC_ATTR void k_uv_fused(DevView d, double gene, double ramp, double ctim) {
+template <bool FIRST_X, bool PROD, bool ZV, bool SF>
+__device__ __forceinline__ void uv_fused_workgroup(const DevView &d, double gene, double ramp, double ctim) {
     __shared__ double s_h[UV_TY + 1][UV_LDX];
     __shared__ UVstage s_f[PROD ? 4 : 1];                    // (ZV: the interior workgroups use two of them, the edge ones all four)
     __shared__ double s_hl[PROD ? UV_HROWS : 1][UV_HLDX];
@@ -1226,6 +1226,20 @@ __global__ __launch_bounds__(UV_BLOCK) UV_OCC_ATTR void k_uv_fused(DevView d, do
     else if (interior) body_uv_fused<FIRST_X, PROD, true, SF>(d, x0, y0, ilay, gene, ramp, ctim, s_h);
     else if (PROD && !d.edge_global) body_uv_fused_edge<FIRST_X, SF>(d, x0, y0, ilay, gene, ramp, ctim, s_h, s_f, s_hl);
     else body_uv_fused<FIRST_X, PROD, false, SF>(d, x0, y0, ilay, gene, ramp, ctim, s_h);
+}
+template <bool FIRST_X, bool PROD, bool ZV = false>
+__global__ __launch_bounds__(UV_BLOCK) UV_OCC_ATTR void k_uv_fused(DevView d, double gene, double ramp, double ctim) {
+    uv_fused_workgroup<FIRST_X, PROD, ZV, false>(d, gene, ramp, ctim);
+}
+// ... with distribute_stress formed inside (SF): its own kernels, so that the unforced ones do not carry its registers.  Their
+// zero-viscosity form takes 129 VGPRs; capped for four waves per SIMD it is slower than left at three (wind-driven
+// 4096x2048x2, same box: u+v 730 vs 714 us)
+template <bool FIRST_X, bool PROD, bool ZV = false>
+#ifndef UV_SF_WAVES_PER_EU
+#define UV_SF_WAVES_PER_EU 3
+#endif
+__global__ __launch_bounds__(UV_BLOCK) __attribute__((amdgpu_waves_per_eu(UV_SF_WAVES_PER_EU))) void k_uv_fused_sf(DevView d, double gene, double ramp, double ctim) {
+    uv_fused_workgroup<FIRST_X, PROD, ZV, true>(d, gene, ramp, ctim);
 }
 static inline dim3 uv_fused_grid(const DevView &d) {
     return dim3(TileMap(d, UV_TX, UV_TY).blocks(), (unsigned)d.nlay, 1);

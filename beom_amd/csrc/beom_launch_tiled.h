@@ -19,10 +19,10 @@ static bool TFN(raw_mont_visc)(beom_engine *E, bool leith) {
 static void TFN(raw_uv_fused)(beom_engine *E, bool first_x, bool prod, bool zv, double gene, double ramp, double ctim) {
     const dim3 g = TNS::uv_fused_grid(E->d), b(TNS::kUvBlock);
     DevView &d = E->d;
-#define UV_GO(fx, pr, z, sf) hipLaunchKernelGGL((TNS::k_uv_fused<fx, pr, z, sf>), g, b, 0, E->stream, d, gene, ramp, ctim)
+#define UV_GO(kern, fx, pr, z) hipLaunchKernelGGL((TNS::kern<fx, pr, z>), g, b, 0, E->stream, d, gene, ramp, ctim)
 #define UV_PICK(fx) do { \
-        if (d.stress_fold) { if (zv) UV_GO(fx, true, true, true); else if (prod) UV_GO(fx, true, false, true); else UV_GO(fx, false, false, true); } \
-        else { if (zv) UV_GO(fx, true, true, false); else if (prod) UV_GO(fx, true, false, false); else UV_GO(fx, false, false, false); } \
+        if (d.stress_fold) { if (zv) UV_GO(k_uv_fused_sf, fx, true, true); else if (prod) UV_GO(k_uv_fused_sf, fx, true, false); else UV_GO(k_uv_fused_sf, fx, false, false); } \
+        else { if (zv) UV_GO(k_uv_fused, fx, true, true); else if (prod) UV_GO(k_uv_fused, fx, true, false); else UV_GO(k_uv_fused, fx, false, false); } \
     } while (0)
     // (stress_fold: distribute_stress formed inside the sweep — its own instantiations, so that the unforced ones stay lean)
     if (first_x) UV_PICK(true); else UV_PICK(false);
