@@ -447,18 +447,28 @@ def _forced_cases():
     }
 
 
+@pytest.mark.parametrize("tile_rows", [4, 8])
 @pytest.mark.parametrize("case", ["wind_only_2l", "wind_linear_drag_1l", "wind_quadratic_bottom_top_drag_3l",
                                   "bottom_drag_only_3l_bodf", "stommel", "mixed_open_bc_wind_sponges"])
-def test_stress_folded_into_momentum_sweep(case):
-    """distribute_stress (private_mod.f95:1921-2149) formed inside the fused u+v sweep: against the oracle, against the same
-    engine with the fold off (its own launch + the three arrays) and on three bands, bit for bit with the sign of zero."""
+def test_stress_folded_into_momentum_sweep(case, tile_rows):
+    """distribute_stress (private_mod.f95:1921-2149) formed inside the fused u+v sweep (k_uv_fused_sf, both tile geometries):
+    against the oracle, against the same engine with the fold off (its own launch + the three arrays) and on three bands, bit
+    for bit with the sign of zero."""
+    import os
     from beom_amd.grid import read_input_data
     p, files = _forced_cases()[case]()
     f = read_input_data(p, files=files)
     obc = bool(f.flag_nudging) and float(p.mcbc) < 0.5
-    fold, plain, o = capi.Engine(f), capi.Engine(f), oracle_lib.Oracle(f)
+    old = os.environ.get("BEOM_TILE4")
+    os.environ["BEOM_TILE4"] = "1" if tile_rows == 4 else "0"          # (read when a handle is created)
+    try:
+        fold, plain, o = capi.Engine(f), capi.Engine(f), oracle_lib.Oracle(f)
+        bands = None if obc else capi.MultiEngine(f, devices=[0, 0, 0])
+    finally:
+        if old is None: os.environ.pop("BEOM_TILE4")
+        else: os.environ["BEOM_TILE4"] = old
+    assert fold.info("tile_rows") == tile_rows
     plain.set_option("fold_stress", 0)
-    bands = None if obc else capi.MultiEngine(f, devices=[0, 0, 0])
     n = 15
     for x in [fold, plain, o] + ([bands] if bands else []):
         x.step(1, 3); x.step(4, n - 3)
