@@ -128,6 +128,20 @@ def test_open_boundaries_on_rank_local_windows(world, case):
     _run(world, case, overlap=True)
 
 
+def test_two_processes_in_the_64x8_tile_geometry():
+    """Bands of the headline frame cut 2 or 4 ways are tall enough for the 64 x 8 tiles: the cut steps in that geometry."""
+    old = os.environ.get("BEOM_TILE4")
+    os.environ["BEOM_TILE4"] = "0"                 # (inherited by the ranks; read when a handle is created)
+    try:
+        _run(2, "closed", overlap=True)
+        _run(2, "jet_ring", overlap=True)
+    finally:
+        if old is None:
+            os.environ.pop("BEOM_TILE4")
+        else:
+            os.environ["BEOM_TILE4"] = old
+
+
 def test_two_processes_plain_exchange_matches_too():
     _run(2, "closed", overlap=False, calls=(5, 1, 7))
 

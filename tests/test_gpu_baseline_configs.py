@@ -120,4 +120,17 @@ def test_headline_4096x4096x4_vs_oracle_and_properties():
     for k in ("hlay", "u", "v"):
         assert same(st[k], sg[k]), k
     assert float(np.max(np.abs(st["u"]))) > 0.0
-    e.close(); g.close()
+    g.close()
+    # (d) the frame as 2 and as 4 row bands — what `bench.py --gpus 2 | 4` gives each GPU: bands tall enough for the 64 x 8
+    #     tile geometry, every step cut boundary first — bit for bit, the sign of zero included
+    from helpers import same_bits
+    for nb in (2, 4):
+        many = capi.MultiEngine(f, devices=[0] * nb)
+        assert many.info("tile_rows") == 8
+        many.step(1, 6)
+        sb = many.download(PROG)
+        for k in PROG:
+            assert same_bits(st[k], sb[k]), (nb, "bands", k)
+        assert many.stats() == {"split": 6 * nb, "plain": 0}
+        many.close()
+    e.close()

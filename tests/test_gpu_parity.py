@@ -573,9 +573,10 @@ def test_profile_start_stop_counts_launches():
     e.close()
 
 
+@pytest.mark.parametrize("tile_rows", [4, 8])
 @pytest.mark.parametrize("case,world", [("closed_tall", 2), ("closed_tall", 3), ("sill_tall", 2), ("beach_tall_noleith", 2),
                                         ("soliton_tall_noleith", 3)])
-def test_cut_step_matches_single_domain(case, world):
+def test_cut_step_matches_single_domain(case, world, tile_rows):
     """beom_step_phase: a band's step in three parts — everything up to the momentum sweeps on all rows, the momentum
     sweep on the strips next to the ghost zones, the same sweep on the rows in between (+ pointer rotations).  Here on one
     stream in program order (the row ranges and the rotations are what is tested; real stream concurrency: next test).
@@ -592,12 +593,20 @@ def test_cut_step_matches_single_domain(case, world):
     else:
         p, files = I.case_sill_exchange3d(lm=133, mm=141, nlay=2, dt_s=0.01, npts=5, sill_halfwidth=6.0)
     f = read_input_data(p, files=files)
-    whole = capi.Engine(f)
-    runs = []
-    for g in slab.decompose(p.mm, p.lm, world):
-        e = capi.Engine(slab.slice_fields(f, g), slab_row0=g.row0, slab_mm=p.mm)
-        runs.append(slab.SlabRunner(e, g, p.nlay, dist=None))
-        e.set_stream(torch.cuda.current_stream().cuda_stream)     # one stream: ordering by program order
+    import os
+    old = os.environ.get("BEOM_TILE4")
+    os.environ["BEOM_TILE4"] = "1" if tile_rows == 4 else "0"          # (read when a handle is created; bands of the headline
+    try:                                                               #  frame cut 2 or 4 ways run the 64 x 8 geometry)
+        whole = capi.Engine(f)
+        runs = []
+        for g in slab.decompose(p.mm, p.lm, world):
+            e = capi.Engine(slab.slice_fields(f, g), slab_row0=g.row0, slab_mm=p.mm)
+            assert e.info("tile_rows") == tile_rows
+            runs.append(slab.SlabRunner(e, g, p.nlay, dist=None))
+            e.set_stream(torch.cuda.current_stream().cuda_stream)     # one stream: ordering by program order
+    finally:
+        if old is None: os.environ.pop("BEOM_TILE4")
+        else: os.environ["BEOM_TILE4"] = old
 
     def move():
         for k in range(world - 1):
